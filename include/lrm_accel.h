@@ -1,0 +1,189 @@
+/*
+ * lrm_accel.h -- C-ABI of liblrm_accel.so, the MI355X (gfx950) implementation
+ * of the seed-and-extend hot path of lisanhu/LongReadMapper (accaln).
+ *
+ * Everything here is extern "C", plain pointers and sizes.  The entry points
+ * are what a maintainer of the reference binds in alnmain.c instead of the
+ * per-read CPU loops (see INTEGRATION.md for the patch):
+ *
+ *   reference (file:line, relative to the reference tree)      replaced by
+ *   ---------------------------------------------------------  ------------------
+ *   init(): index arrays resident in host RAM                   lrm_index_upload
+ *     alnmain.c:179-256, fmidx.h:16-28, lchash.h:16-20
+ *   PART 1 seed + vote loop, alnmain.c:333-405                  lrm_seed_batch
+ *     lc_aln lchash.h:25-27, fmi_aln fmidx.h:37-38,
+ *     sa_access fmidx.h:30, histo_* histo.h:32-37
+ *   PART 2 locus resolve + rev-comp + extension,                lrm_extend_batch
+ *     alnmain.c:408-451, cigar_align mutils.h:57-58
+ *   PART 3 result flags, alnmain.c:458-477                      lrm_result_flags
+ *   context_destroy(), accaln.c:7-43                            lrm_index_free
+ *
+ * Struct mirrors keep the reference's field order so the reference's own
+ * objects can be passed by pointer cast (dna_fmi*, lc_hash*, entry*, params).
+ *
+ * There is NO CPU fallback: every batch call fails (negative return,
+ * lrm_last_error()) when no gfx950 device / code object is available.
+ *
+ * Return convention: 0 = ok, <0 = error (message via lrm_last_error()).
+ * Data-level conventions of the reference are preserved: 0 seed hits, score
+ * -1 = alignment failure, meta_r 0 = locus outside every sequence.
+ */
+#ifndef LRM_ACCEL_H
+#define LRM_ACCEL_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRM_ABI_VERSION 1
+
+/* histo/histo.h:21-23 `entry` */
+typedef struct lrm_entry { uint64_t key, val, bucket; } lrm_entry;
+
+/* alnmain.h:10-13 `params` */
+typedef struct lrm_params { uint64_t batch_size; uint32_t seed_len, thres; } lrm_params;
+
+/* fmidx/fmidx.h:16-21 `dna_fmi` (identical field order) */
+typedef struct lrm_dna_fmi {
+    uint64_t length, o_len, csa_len;
+    uint64_t *c, *o, *csa;
+    int o_ratio, csa_ratio;
+    char *bwt;
+} lrm_dna_fmi;
+
+/* lchash/lchash.h:16-20 `lc_hash` */
+typedef struct lrm_lc_hash { uint64_t *lc; uint64_t len; int hlen; } lrm_lc_hash;
+
+/* psascan/sa_use.h:17-20 `ui40_t` as it sits in RAM (8 bytes with padding) and
+ * fmidx/fmidx.h:23-26 `sa_mem` */
+typedef struct lrm_ui40 { uint32_t low; uint8_t high; } lrm_ui40;
+typedef struct lrm_sa_mem { uint64_t start, len; lrm_ui40 *mem; } lrm_sa_mem;
+
+/* accaln.h:67-71 `mta_entry` flattened: {mstring seq_name{l,s,own}; offset; seq_len} */
+typedef struct lrm_mta_entry {
+    uint64_t name_len; char *name; int name_own;
+    uint64_t offset; size_t seq_len;
+} lrm_mta_entry;
+
+/* alnmain.c:143-148 `seq_meta`; g_name is returned as the index of the mta entry */
+typedef struct lrm_seq_meta { uint64_t loc, off; int32_t seq_id; uint8_t strand; } lrm_seq_meta;
+
+/* gact `cigar` as used at mutils.c:97-103 / alnmain.c:314-325: one op byte per
+ * alignment column ('=' 'X' 'I' 'D') in a caller-owned buffer */
+typedef struct lrm_cigar { uint8_t *cigar; int n_cigar_op; int score; } lrm_cigar;
+
+/* GACT tile / overlap / band (docs/GACT_SPEC.md); {0,0,0} selects the defaults */
+typedef struct lrm_gact_params { int T, O, W; } lrm_gact_params;
+#define LRM_GACT_T_DEFAULT 320
+#define LRM_GACT_O_DEFAULT 120
+#define LRM_GACT_W_DEFAULT 128
+
+typedef struct lrm_index lrm_index;       /* opaque: device-resident index */
+
+const char *lrm_last_error(void);
+int lrm_abi_version(void);
+/* number of visible HIP devices (<=0: none). Does not fail loudly: probing only. */
+int lrm_device_count(void);
+
+/* ---------------------------------------------------------------------------
+ * Index: host arrays in the reference's in-memory layout -> device image
+ * ------------------------------------------------------------------------- */
+
+/* Size in bytes of the device image ("blob") for an index of these dimensions. */
+uint64_t lrm_index_blob_bytes(uint64_t length, int hlen, int mta_len);
+
+/* Serialise the reference-layout arrays into the device image, in host memory
+ * (blob must hold lrm_index_blob_bytes()).  Pure CPU; usable without a GPU.
+ * sa: sa_len elements of ui40 in RAM (8-byte stride), as filled by ui40_fread. */
+int lrm_index_pack_blob(const lrm_dna_fmi *fmi, const lrm_lc_hash *lch,
+                        const lrm_sa_mem *sa, const char *content, uint64_t con_len,
+                        const lrm_mta_entry *mta, int mta_len, void *blob, uint64_t blob_bytes);
+
+/* One-call upload used behind alnmain.c:init(): pack + hipMemcpy to `device`. */
+int lrm_index_upload(lrm_index **out, const lrm_dna_fmi *fmi, const lrm_lc_hash *lch,
+                     const lrm_sa_mem *sa, const char *content, uint64_t con_len,
+                     const lrm_mta_entry *mta, int mta_len, int device);
+
+/* Adopt a blob that already sits in device memory (e.g. the destination of an
+ * RCCL broadcast).  The blob is borrowed: it must outlive the handle. */
+int lrm_index_adopt_device(lrm_index **out, void *d_blob, uint64_t blob_bytes, int device);
+
+/* Upload a host blob (copy). */
+int lrm_index_upload_blob(lrm_index **out, const void *blob, uint64_t blob_bytes, int device);
+
+void lrm_index_free(lrm_index *idx);
+
+/* ---------------------------------------------------------------------------
+ * Batch entry points with HOST buffers (the drop-in boundary)
+ * ------------------------------------------------------------------------- */
+
+/* PART 1.  reads_buf: dense buffer, read i at reads_buf + i*stride, lens[i]
+ * bases, upper-case ACGT (alnmain.c:87-103 layout, stride = max_read_len+1).
+ * best_out[i] = the candidate entry the reference leaves in best[chunk_i]. */
+int lrm_seed_batch(lrm_index *idx, const char *reads_buf, uint64_t stride,
+                   const uint32_t *lens, uint64_t n, lrm_params p, lrm_entry *best_out);
+
+/* PART 2.  Reads whose locus resolves to the reverse strand are reverse-
+ * complemented IN PLACE in reads_buf (alnmain.c:433-438).  cig_out[i].cigar is
+ * set to store_mem + i*store_stride (store_stride >= 2*lens[i]);
+ * score_out[i] = cig_out[i].score (the value the reference writes to limit[]). */
+int lrm_extend_batch(lrm_index *idx, char *reads_buf, uint64_t stride,
+                     const uint32_t *lens, uint64_t n, const lrm_entry *best,
+                     lrm_gact_params gp, lrm_cigar *cig_out, uint8_t *store_mem,
+                     uint64_t store_stride, int *score_out, lrm_seq_meta *meta_out,
+                     int *meta_r_out);
+
+/* PART 3 flag/mapq/valid assembly (alnmain.c:460-474); pure host arithmetic. */
+void lrm_result_flags(const int *score, const int *meta_r, const lrm_seq_meta *meta,
+                      uint64_t n, int *flag_out, int *mapq_out, int *valid_out);
+
+/* ---------------------------------------------------------------------------
+ * Batch entry points with DEVICE buffers (inputs/outputs resident in HBM;
+ * asynchronous on `stream`, a hipStream_t passed as void*, may be NULL).
+ * ------------------------------------------------------------------------- */
+
+typedef struct lrm_workspace lrm_workspace;   /* opaque: device scratch for a batch shape */
+
+/* Scratch for batches of up to n_max reads of up to max_len bases. */
+int lrm_workspace_create(lrm_workspace **out, lrm_index *idx, uint64_t n_max,
+                         uint32_t max_len, uint32_t seed_len, uint32_t thres);
+void lrm_workspace_free(lrm_workspace *ws);
+uint64_t lrm_workspace_bytes(const lrm_workspace *ws);
+
+int lrm_seed_batch_dev(lrm_index *idx, lrm_workspace *ws, const char *d_reads,
+                       uint64_t stride, const uint32_t *d_lens, uint64_t n,
+                       uint32_t max_len, lrm_params p, lrm_entry *d_best, void *stream);
+
+int lrm_extend_batch_dev(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint64_t stride,
+                         const uint32_t *d_lens, uint64_t n, uint32_t max_len,
+                         const lrm_entry *d_best, lrm_gact_params gp, uint8_t *d_store,
+                         uint64_t store_stride, int32_t *d_n_ops, int32_t *d_score,
+                         lrm_seq_meta *d_meta, int32_t *d_meta_r, void *stream);
+
+/* Counters of the last *_dev call on this workspace (device->host copy, syncs
+ * the stream): reads that needed the global-memory vote table, seed phases
+ * evaluated, GACT tiles.  For tests / bench bookkeeping only. */
+typedef struct lrm_stats {
+    uint64_t vote_overflow_items;   /* (read,phase) items re-run with the global table */
+    uint64_t reads_decided_phase0;  /* reads whose vote passed 0.6 in phase 0 */
+    uint64_t gact_tiles;
+} lrm_stats;
+int lrm_workspace_stats(lrm_workspace *ws, lrm_stats *out, void *stream);
+
+/* Debug/parity taps (tests only): per-seed search results of one read as the
+ * seed kernel produced them, in (phase, ordinal) order: j, rr, k, l. */
+int lrm_debug_seed_search(lrm_index *idx, const char *read, uint32_t len, uint32_t seed_len,
+                          uint32_t thres, int32_t *j_out, uint64_t *rr_out, uint64_t *k_out,
+                          uint64_t *l_out, uint64_t cap, uint64_t *n_out);
+
+/* Direct kernel tap (tests only): simple_gact on one (q, d) pair. */
+int lrm_debug_gact(const char *q, int n, const char *d, int m, lrm_gact_params gp,
+                   uint8_t *ops, int *n_ops, int *score, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRM_ACCEL_H */

@@ -1,0 +1,73 @@
+"""Build the native libraries in-tree (no JIT cache: the .so files travel with the repo).
+
+  liblrm_accel.so  hipcc --offload-arch=gfx950 : HIP kernels + C-ABI + CPU index builder
+  liblrm_synth.so  g++ -fopenmp                : synthetic reference / read generators (tooling)
+
+hipcc cross-compiles gfx950 without a GPU, so this runs in the CPU-only build container.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+
+ACCEL_SRCS = ["lrm_api.hip", "seed_kernels.hip", "gact_kernels.hip", "index_host.cpp"]
+ACCEL_DEPS = ACCEL_SRCS + ["lrm_internal.h", "../../include/lrm_accel.h", "../../include/lrm_index_host.h"]
+ACCEL_LIB = os.path.join(HERE, "liblrm_accel.so")
+SYNTH_LIB = os.path.join(HERE, "liblrm_synth.so")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def hipcc_path():
+    for p in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if p and os.path.exists(p):
+            return p
+    return None
+
+
+def build_accel(force=False):
+    deps = [os.path.join(CSRC, d) for d in ACCEL_DEPS]
+    if not force and not _stale(ACCEL_LIB, deps):
+        return ACCEL_LIB
+    hipcc = hipcc_path()
+    if hipcc is None:
+        if os.path.exists(ACCEL_LIB):
+            return ACCEL_LIB        # GPU box without a compiler on PATH: use the prebuilt library
+        raise RuntimeError("hipcc not found and no prebuilt liblrm_accel.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fopenmp",
+           "-I" + os.path.join(ROOT, "include")]
+    cmd += [os.path.join(CSRC, s) for s in ACCEL_SRCS]
+    cmd += ["-o", ACCEL_LIB]
+    _run(cmd)
+    return ACCEL_LIB
+
+
+def build_synth(force=False):
+    src = os.path.join(CSRC, "synth.cpp")
+    if not force and not _stale(SYNTH_LIB, [src]):
+        return SYNTH_LIB
+    _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", src, "-o", SYNTH_LIB])
+    return SYNTH_LIB
+
+
+def build_all(force=False):
+    return build_accel(force), build_synth(force)
+
+
+if __name__ == "__main__":
+    print(build_all(force=True))

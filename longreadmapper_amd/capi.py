@@ -1,0 +1,149 @@
+"""ctypes binding of liblrm_accel.so (include/lrm_accel.h, include/lrm_index_host.h).
+
+This is what a Python host would bind; the structs mirror the reference's own
+(accaln.h / alnmain.h / fmidx.h / lchash.h / histo.h).  There is no fallback: if the
+library is missing the import of this module fails loudly.
+"""
+import ctypes as C
+import os
+
+from . import _build
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+i32p = C.POINTER(C.c_int32)
+
+
+class Entry(C.Structure):              # histo.h:21-23
+    _fields_ = [("key", C.c_uint64), ("val", C.c_uint64), ("bucket", C.c_uint64)]
+
+
+class Params(C.Structure):             # alnmain.h:10-13
+    _fields_ = [("batch_size", C.c_uint64), ("seed_len", C.c_uint32), ("thres", C.c_uint32)]
+
+
+class DnaFmi(C.Structure):             # fmidx.h:16-21
+    _fields_ = [("length", C.c_uint64), ("o_len", C.c_uint64), ("csa_len", C.c_uint64),
+                ("c", u64p), ("o", u64p), ("csa", u64p),
+                ("o_ratio", C.c_int), ("csa_ratio", C.c_int), ("bwt", C.c_void_p)]
+
+
+class LcHash(C.Structure):             # lchash.h:16-20
+    _fields_ = [("lc", u64p), ("len", C.c_uint64), ("hlen", C.c_int)]
+
+
+class Ui40(C.Structure):               # sa_use.h:17-20 (8 bytes in RAM)
+    _fields_ = [("low", C.c_uint32), ("high", C.c_uint8)]
+
+
+class SaMem(C.Structure):              # fmidx.h:23-26
+    _fields_ = [("start", C.c_uint64), ("len", C.c_uint64), ("mem", C.POINTER(Ui40))]
+
+
+class MtaEntry(C.Structure):           # accaln.h:67-71 flattened
+    _fields_ = [("name_len", C.c_uint64), ("name", C.c_char_p), ("name_own", C.c_int),
+                ("offset", C.c_uint64), ("seq_len", C.c_size_t)]
+
+
+class SeqMeta(C.Structure):            # alnmain.c:143-148
+    _fields_ = [("loc", C.c_uint64), ("off", C.c_uint64), ("seq_id", C.c_int32), ("strand", C.c_uint8)]
+
+
+class Cigar(C.Structure):              # gact cigar (mutils.c:97-103)
+    _fields_ = [("cigar", u8p), ("n_cigar_op", C.c_int), ("score", C.c_int)]
+
+
+class GactParams(C.Structure):
+    _fields_ = [("T", C.c_int), ("O", C.c_int), ("W", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("vote_overflow_items", C.c_uint64), ("reads_decided_phase0", C.c_uint64),
+                ("gact_tiles", C.c_uint64)]
+
+
+class HostIndex(C.Structure):          # lrm_index_host.h
+    _fields_ = [("fmi", DnaFmi), ("lch", LcHash), ("sa", SaMem), ("content", C.c_void_p),
+                ("con_len", C.c_uint64), ("mta", C.POINTER(MtaEntry)), ("mta_len", C.c_int)]
+
+
+assert C.sizeof(Ui40) == 8 and C.sizeof(Entry) == 24 and C.sizeof(SeqMeta) == 24
+
+# every symbol include/*.h declares: (restype, argtypes)
+SYMBOLS = {
+    "lrm_last_error": (C.c_char_p, []),
+    "lrm_abi_version": (C.c_int, []),
+    "lrm_device_count": (C.c_int, []),
+    "lrm_index_blob_bytes": (C.c_uint64, [C.c_uint64, C.c_int, C.c_int]),
+    "lrm_index_pack_blob": (C.c_int, [C.POINTER(DnaFmi), C.POINTER(LcHash), C.POINTER(SaMem), C.c_void_p,
+                                      C.c_uint64, C.POINTER(MtaEntry), C.c_int, C.c_void_p, C.c_uint64]),
+    "lrm_index_upload": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(DnaFmi), C.POINTER(LcHash),
+                                   C.POINTER(SaMem), C.c_void_p, C.c_uint64, C.POINTER(MtaEntry), C.c_int, C.c_int]),
+    "lrm_index_adopt_device": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_int]),
+    "lrm_index_upload_blob": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_int]),
+    "lrm_index_free": (None, [C.c_void_p]),
+    "lrm_seed_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, Params, C.c_void_p]),
+    "lrm_extend_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                   GactParams, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "lrm_result_flags": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lrm_workspace_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
+                                       C.c_uint32]),
+    "lrm_workspace_free": (None, [C.c_void_p]),
+    "lrm_workspace_bytes": (C.c_uint64, [C.c_void_p]),
+    "lrm_seed_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                     C.c_uint32, Params, C.c_void_p, C.c_void_p]),
+    "lrm_extend_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                       C.c_uint32, C.c_void_p, GactParams, C.c_void_p, C.c_uint64, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lrm_workspace_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats), C.c_void_p]),
+    "lrm_debug_seed_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, u64p]),
+    "lrm_debug_gact": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, GactParams, C.c_void_p,
+                                 C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
+    # lrm_index_host.h
+    "lrm_cat_from_seqs": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u64p, C.c_int, C.c_uint64,
+                                    C.POINTER(C.c_void_p), u64p, C.POINTER(C.POINTER(MtaEntry))]),
+    "lrm_sa_build": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "lrm_host_index_build": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(MtaEntry), C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(HostIndex)]),
+    "lrm_host_index_free": (None, [C.POINTER(HostIndex)]),
+    "lrm_host_index_write": (C.c_int, [C.POINTER(HostIndex), C.c_char_p]),
+    "lrm_host_index_read": (C.c_int, [C.c_char_p, C.POINTER(HostIndex)]),
+    "lrm_fmi_write": (C.c_int, [C.POINTER(DnaFmi), C.c_char_p]),
+    "lrm_fmi_read": (C.c_int, [C.POINTER(DnaFmi), C.c_char_p]),
+    "lrm_lc_write": (C.c_int, [C.c_char_p, C.POINTER(LcHash)]),
+    "lrm_lc_read": (C.c_int, [C.c_char_p, C.POINTER(LcHash)]),
+    "lrm_sa5_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64]),
+    "lrm_sa5_read": (C.c_int64, [C.c_char_p, C.c_void_p, C.c_uint64]),
+    "lrm_mta_write": (C.c_int, [C.c_char_p, C.POINTER(MtaEntry), C.c_int]),
+    "lrm_mta_read": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(MtaEntry))]),
+    "lrm_mta_free": (None, [C.POINTER(MtaEntry), C.c_int]),
+    "lrm_accidx": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_uint64]),
+}
+
+
+def _load():
+    path = _build.ACCEL_LIB
+    if not os.path.exists(path):
+        path = _build.build_accel()
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class LrmError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc < 0:
+        raise LrmError("%s: %s" % (what or "liblrm_accel", lib.lrm_last_error().decode(errors="replace")))
+    return rc

@@ -1,0 +1,377 @@
+// gact_kernels.hip -- gfx950 kernels for PART 2 of the accaln hot path
+// (reference: alnmain.c:408-451 -- seq_lookup :151-176, _rev_comp_in_place :27-60,
+//  cigar_align mutils.c:94-105 -> simple_gact [gact submodule, source absent]).
+//
+//   locus_resolve  one lane per read: seq_lookup with the reference's u64 arithmetic
+//   revcomp        reverse-complement reads that resolved to the reverse strand, in place
+//   gact           ONE WAVEFRONT PER READ; tiles of the read are walked in sequence
+//                  (tile i+1 starts where tile i's traceback stopped), docs/GACT_SPEC.md.
+//
+// GACT tile on a 64-lane wavefront: the band (<=128 diagonals) is laid across the lanes and
+// the wavefront sweeps anti-diagonals s = a+b from the far corner down to the anchor.  On an
+// even s lane L owns diagonal d = 2L-64, on an odd s diagonal d = 2L-63, so every lane computes
+// one lattice point per step (no idle parity) and the three neighbours are: own lane two steps
+// ago (DIAG), own lane / lane-1 (INS) and own lane / lane+1 (DEL) one step ago -- a single DPP
+// wave shift per step, no LDS traffic for scores.  Traceback pointers (2 bit/point) are packed
+// 16 steps per dword and parked in LDS; the traceback walk reads them back.  Integer max/add
+// recurrences: nothing here is a contraction, MFMA does not apply.
+#include <hip/hip_runtime.h>
+#include "lrm_internal.h"
+
+#define GACT_NEG (-(1 << 28))
+#define GACT_PAD 96          // guard bytes on both sides of the staged sequences
+#define DPP_WAVE_SHL1 0x130  // lane L <- lane L+1
+#define DPP_WAVE_SHR1 0x138  // lane L <- lane L-1
+
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void locus_resolve_kernel(LrmIndexView ix, const lrm_entry *__restrict__ best,
+                                                            const uint32_t *__restrict__ lens, uint64_t n,
+                                                            lrm_seq_meta *__restrict__ meta,
+                                                            int32_t *__restrict__ meta_r) {
+    uint64_t read = (uint64_t) blockIdx.x * 256 + threadIdx.x;
+    if (read >= n) return;
+    const uint64_t loc = best[read].key;                       // alnmain.c:427
+    const uint32_t qlen = lens[read];
+    lrm_seq_meta m;
+    m.loc = 0; m.off = 0; m.seq_id = -1; m.strand = 0;
+    int mr = 0;
+    for (int i = 0; i < ix.mta_len; ++i) {                     // alnmain.c:155-174
+        uint64_t sl = ix.mta[i].seq_len;
+        uint64_t start = ix.mta[i].offset;
+        uint64_t end = start + sl * 2;
+        if (loc >= start && loc + qlen <= start + sl) {
+            m.strand = 0; m.seq_id = i; m.loc = loc; m.off = loc - start;
+            mr = 1;
+            break;
+        } else if (loc >= start + sl && loc + qlen <= end) {
+            m.strand = 1; m.seq_id = i; m.off = end - loc - qlen; m.loc = m.off + start;
+            mr = 1;
+            break;
+        }
+    }
+    // Fences: the reference consumes an uninitialised struct when the lookup fails,
+    // and a wrapped u64 locus can pass the test while pointing outside the text.
+    if (mr && (qlen == 0 || m.loc >= ix.con_len || (uint64_t) qlen > ix.con_len - m.loc)) mr = 0;
+    if (!mr) { m.loc = 0; m.off = 0; m.seq_id = -1; m.strand = 0; }
+    meta[read] = m;
+    meta_r[read] = mr;
+}
+
+__device__ __forceinline__ char comp_base(char c) {           // alnmain.c:31-52
+    switch (c) {
+        case 'A': case 'a': return 'T';
+        case 'C': case 'c': return 'G';
+        case 'G': case 'g': return 'C';
+        case 'T': case 't': return 'A';
+        default: return 'N';
+    }
+}
+
+__global__ __launch_bounds__(256) void revcomp_kernel(char *__restrict__ reads, uint64_t stride,
+                                                      const uint32_t *__restrict__ lens,
+                                                      const lrm_seq_meta *__restrict__ meta,
+                                                      const int32_t *__restrict__ meta_r, uint64_t n,
+                                                      uint32_t chunks_per_read) {
+    uint64_t read = blockIdx.x / chunks_per_read;
+    uint32_t chunk = blockIdx.x % chunks_per_read;
+    if (read >= n) return;
+    if (!meta_r[read] || meta[read].strand != 1) return;       // alnmain.c:433
+    uint32_t len = lens[read];
+    uint32_t x = chunk * 256 + threadIdx.x;
+    uint32_t half = (len + 1) / 2;
+    if (x >= half) return;
+    char *r = reads + read * stride;
+    uint32_t y = len - 1 - x;
+    char cx = comp_base(r[x]);
+    if (x == y) { r[x] = cx; return; }
+    char cy = comp_base(r[y]);
+    r[x] = cy;
+    r[y] = cx;
+}
+
+// ----------------------------------------------------------------------------------------
+// GACT
+// ----------------------------------------------------------------------------------------
+struct GactLds {
+    uint32_t tb_words;     // dwords of traceback per lane
+    uint32_t seq_bytes;    // bytes of one staged sequence incl. both pads
+    uint32_t ops_bytes;
+    uint32_t wave_bytes;   // total per wavefront
+};
+
+__host__ __device__ inline GactLds gact_lds_layout(int T) {
+    GactLds g;
+    g.tb_words = (uint32_t) (2 * T) / 16 + 1;
+    g.seq_bytes = ((uint32_t) T + 2 * GACT_PAD + 15u) & ~15u;
+    g.ops_bytes = ((uint32_t) (2 * T) + 15u) & ~15u;
+    g.wave_bytes = g.tb_words * 64 * 4 + 2 * g.seq_bytes + g.ops_bytes;
+    return g;
+}
+
+__device__ __forceinline__ int dpp_from_lower(int v, int fill) {   // lane L <- lane L-1, lane 0 <- fill
+    return __builtin_amdgcn_update_dpp(fill, v, DPP_WAVE_SHR1, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int dpp_from_upper(int v, int fill) {   // lane L <- lane L+1, lane 63 <- fill
+    return __builtin_amdgcn_update_dpp(fill, v, DPP_WAVE_SHL1, 0xf, 0xf, false);
+}
+
+// one DP step for this lane's lattice point; returns new R, appends the 2-bit pointer to acc
+__device__ __forceinline__ int gact_cell(int r_diag, int r_ins, int r_del, uint32_t qc, uint32_t dc,
+                                         bool is_exit, bool inband, uint32_t &acc) {
+    int cd = r_diag + (qc == dc ? 1 : -1);
+    int ci = r_ins - 1, cl = r_del - 1;
+    int m1 = ci >= cl ? ci : cl;
+    uint32_t p1 = ci >= cl ? 1u : 2u;          // INS before DEL on ties
+    bool diag = cd >= m1;                      // DIAG wins ties
+    int best = diag ? cd : m1;
+    uint32_t p = diag ? 0u : p1;
+    best = is_exit ? 0 : best;
+    best = inband ? best : GACT_NEG;
+    acc = (acc << 2) | p;
+    return best;
+}
+
+__global__ __launch_bounds__(256) void gact_kernel(const char *__restrict__ reads, uint64_t stride,
+                                                   const uint32_t *__restrict__ lens,
+                                                   const lrm_seq_meta *__restrict__ meta,
+                                                   const int32_t *__restrict__ meta_r,
+                                                   const char *__restrict__ content,
+                                                   const uint32_t *__restrict__ tlens, uint64_t n_reads,
+                                                   int T, int O, int W, uint8_t *__restrict__ store,
+                                                   uint64_t store_stride, int32_t *__restrict__ n_ops_out,
+                                                   int32_t *__restrict__ score_out, LrmDevCounters *counters) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t read = (uint64_t) blockIdx.x * 4 + wave;
+    if (read >= n_reads) return;
+    if (!meta_r[read]) {                       // fenced: no extension (reference would read garbage)
+        if (lane == 0) { n_ops_out[read] = 0; score_out[read] = -1; }
+        return;
+    }
+    const GactLds L = gact_lds_layout(T);
+    uint8_t *base = smem + (size_t) wave * L.wave_bytes;
+    uint32_t *tb = reinterpret_cast<uint32_t *>(base);
+    uint8_t *qbuf = base + (size_t) L.tb_words * 256 + GACT_PAD;
+    uint8_t *dbuf = qbuf + L.seq_bytes;
+    uint8_t *opsbuf = base + (size_t) L.tb_words * 256 + 2 * L.seq_bytes;
+
+    const int n = (int) lens[read];
+    const int m = tlens ? (int) tlens[read] : n;                 // alnmain.c:443-445: tlen == qlen
+    const uint8_t *q = reinterpret_cast<const uint8_t *>(reads) + read * stride;
+    const uint8_t *d = reinterpret_cast<const uint8_t *>(content) + meta[read].loc;
+    uint8_t *ops_out = store + read * store_stride;
+
+    const int hw = W / 2;
+    const int dE = 2 * lane - 64, dO = 2 * lane - 63;
+    const bool inE = dE >= -hw && dE < hw, inO = dO >= -hw && dO < hw;
+    const int cap = T - O;
+
+    int i = 0, j = 0, nops = 0, score = 0;
+    unsigned tiles = 0;
+
+    while (i < n && j < m) {
+        const int tq = (n - i) < T ? (n - i) : T;
+        const int tt = (m - j) < T ? (m - j) : T;
+        const bool last = (i + tq == n);
+        tiles++;
+        // stage the tile's sequences in LDS (coalesced byte loads)
+        for (int x = lane; x < tq; x += 64) qbuf[x] = q[i + x];
+        for (int x = lane; x < tt; x += 64) dbuf[x] = d[j + x];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        const int eE = min(2 * tq + dE, 2 * tt - dE);            // first step at/after which lane is exit/outside
+        const int eO = min(2 * tq + dO, 2 * tt - dO);
+        int r1 = GACT_NEG, r2 = GACT_NEG;                        // R at s+1 and s+2 for this lane
+        uint32_t acc = 0;
+        int s = tq + tt;
+        // per-lane coordinates at the current step
+        uint32_t qc = 0, dc = 0;
+        if ((s & 1) == 0) {
+            // even head step: a = s/2+32-lane, b = s/2-32+lane
+            int a = s / 2 + 32 - lane, b = s / 2 - 32 + lane;
+            qc = qbuf[a]; dc = dbuf[b];
+            int ins = dpp_from_lower(r1, GACT_NEG);
+            int r0 = gact_cell(r2, ins, r1, qc, dc, s >= eE, inE, acc);
+            r2 = r1; r1 = r0;
+            if ((s & 15) == 0) { tb[(s >> 4) * 64 + lane] = acc; }
+            s--;
+        } else {
+            // prime chars for the odd/even pair loop: the odd step reloads qc, keeps dc
+            int b = (s - 1) / 2 - 31 + lane;                     // b at odd s
+            dc = dbuf[b];
+        }
+        // pair loop: odd step s, then even step s-1
+        for (; s >= 1; s -= 2) {
+            {   // odd: a = (s-1)/2+32-lane (decremented), b unchanged
+                int a = (s - 1) / 2 + 32 - lane;
+                qc = qbuf[a];
+                int del = dpp_from_upper(r1, GACT_NEG);
+                int r0 = gact_cell(r2, r1, del, qc, dc, s >= eO, inO, acc);
+                r2 = r1; r1 = r0;
+            }
+            {   // even: s-1; b = (s-1)/2-32+lane (decremented), a unchanged
+                int se = s - 1;
+                int b = se / 2 - 32 + lane;
+                dc = dbuf[b];
+                int ins = dpp_from_lower(r1, GACT_NEG);
+                int r0 = gact_cell(r2, ins, r1, qc, dc, se >= eE, inE, acc);
+                r2 = r1; r1 = r0;
+                if ((se & 15) == 0) { tb[(se >> 4) * 64 + lane] = acc; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // traceback walk from the anchor (uniform across the wavefront)
+        int a = 0, b = 0, cnt = 0;
+        while (a < tq && b < tt && (last || (a < cap && b < cap))) {
+            int sw = a + b, dd = b - a;
+            uint32_t word = tb[(sw >> 4) * 64 + ((dd + 64) >> 1)];
+            uint32_t p = (word >> (2 * (sw & 15))) & 3u;
+            p = __builtin_amdgcn_readfirstlane(p);
+            uint8_t op;
+            if (p == 0) {
+                bool eq = qbuf[a] == dbuf[b];
+                op = eq ? '=' : 'X';
+                score += eq ? 0 : 1;
+                a++; b++;
+            } else if (p == 1) {
+                op = 'I'; score++; a++;
+            } else {
+                op = 'D'; score++; b++;
+            }
+            if (lane == 0) opsbuf[cnt] = op;
+            cnt++;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int x = lane; x < cnt; x += 64) ops_out[nops + x] = opsbuf[x];
+        nops += cnt;
+        i += a;
+        j += b;
+        if (a + b == 0) { score = -1; break; }                   // cannot happen (T-O >= 1); never spin
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (score >= 0 && i < n) {                                   // target exhausted: rest of the query is inserted
+        int rest = n - i;
+        for (int x = lane; x < rest; x += 64) ops_out[nops + x] = 'I';
+        nops += rest;
+        score += rest;
+    }
+    if (lane == 0) {
+        n_ops_out[read] = score >= 0 ? nops : 0;
+        score_out[read] = score;
+        atomicAdd(&counters->gact_tiles, (unsigned long long) tiles);
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    lrm_set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
+
+int lrm_launch_extend(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint64_t stride,
+                      const uint32_t *d_lens, uint64_t n, uint32_t max_len,
+                      const lrm_entry *d_best, lrm_gact_params gp, uint8_t *d_store,
+                      uint64_t store_stride, int32_t *d_n_ops, int32_t *d_score,
+                      lrm_seq_meta *d_meta, int32_t *d_meta_r, void *stream_) {
+    hipStream_t stream = (hipStream_t) stream_;
+    if (n == 0) return 0;
+    if (gp.T == 0 && gp.O == 0 && gp.W == 0) {
+        gp.T = LRM_GACT_T_DEFAULT; gp.O = LRM_GACT_O_DEFAULT; gp.W = LRM_GACT_W_DEFAULT;
+    }
+    if (gp.T < 16 || gp.T > 512 || gp.O < 0 || gp.O >= gp.T || gp.W < 2 || (gp.W & 1) || gp.W > 128) {
+        lrm_set_error("unsupported GACT parameters T=%d O=%d W=%d (need 16<=T<=512, 0<=O<T, even 2<=W<=128)",
+                      gp.T, gp.O, gp.W);
+        return -1;
+    }
+    if (store_stride < 2ull * max_len) {
+        lrm_set_error("store_stride %llu < 2*max_len %u", (unsigned long long) store_stride, max_len);
+        return -1;
+    }
+    hipLaunchKernelGGL(locus_resolve_kernel, dim3((uint32_t) ((n + 255) / 256)), dim3(256), 0, stream,
+                       idx->view, d_best, d_lens, n, d_meta, d_meta_r);
+    {
+        uint32_t cpr = ((max_len + 1) / 2 + 255) / 256;
+        if (cpr == 0) cpr = 1;
+        uint64_t blocks = n * cpr;
+        if (blocks > 0x7fffffffull) { lrm_set_error("revcomp grid too large: split the batch"); return -1; }
+        hipLaunchKernelGGL(revcomp_kernel, dim3((uint32_t) blocks), dim3(256), 0, stream, d_reads, stride,
+                           d_lens, d_meta, d_meta_r, n, cpr);
+    }
+    {
+        GactLds L = gact_lds_layout(gp.T);
+        size_t shmem = (size_t) L.wave_bytes * 4;
+        static size_t configured = 0;
+        if (shmem > 64 * 1024 && shmem > configured) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gact_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem));
+            configured = shmem;
+        }
+        uint64_t blocks = (n + 3) / 4;
+        hipLaunchKernelGGL(gact_kernel, dim3((uint32_t) blocks), dim3(256), shmem, stream, d_reads, stride,
+                           d_lens, d_meta, d_meta_r, idx->view.content, (const uint32_t *) nullptr, n, gp.T, gp.O,
+                           gp.W, d_store,
+                           store_stride, d_n_ops, d_score, ws->d_counters);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// direct kernel tap (tests only): simple_gact on one (q, d) pair, m may differ from n
+extern "C" int lrm_debug_gact(const char *q, int n, const char *d, int m, lrm_gact_params gp, uint8_t *ops,
+                              int *n_ops, int *score, int device) {
+    if (!q || !d || !ops || !n_ops || !score || n < 0 || m < 0) { lrm_set_error("bad argument"); return -1; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        lrm_set_error("no HIP device available: liblrm_accel has no CPU fallback");
+        return -1;
+    }
+    HIPCHK(hipSetDevice(device));
+    if (gp.T == 0 && gp.O == 0 && gp.W == 0) {
+        gp.T = LRM_GACT_T_DEFAULT; gp.O = LRM_GACT_O_DEFAULT; gp.W = LRM_GACT_W_DEFAULT;
+    }
+    if (gp.T < 16 || gp.T > 512 || gp.O < 0 || gp.O >= gp.T || gp.W < 2 || (gp.W & 1) || gp.W > 128) {
+        lrm_set_error("unsupported GACT parameters T=%d O=%d W=%d", gp.T, gp.O, gp.W);
+        return -1;
+    }
+    char *dq = nullptr, *dd = nullptr;
+    uint8_t *dops = nullptr;
+    uint32_t *dl = nullptr;
+    lrm_seq_meta *dm = nullptr;
+    int32_t *dr = nullptr;
+    LrmDevCounters *dc = nullptr;
+    HIPCHK(hipMalloc(&dq, (size_t) n + 16));
+    HIPCHK(hipMalloc(&dd, (size_t) m + 16));
+    HIPCHK(hipMalloc(&dops, (size_t) n + m + 16));
+    HIPCHK(hipMalloc(&dl, 16));
+    HIPCHK(hipMalloc(&dm, sizeof(lrm_seq_meta)));
+    HIPCHK(hipMalloc(&dr, 16));
+    HIPCHK(hipMalloc(&dc, sizeof(LrmDevCounters)));
+    HIPCHK(hipMemset(dc, 0, sizeof(LrmDevCounters)));
+    uint32_t hl[2] = {(uint32_t) n, (uint32_t) m};
+    lrm_seq_meta hm; hm.loc = 0; hm.off = 0; hm.seq_id = 0; hm.strand = 0;
+    int32_t hr[3] = {1, 0, 0};
+    HIPCHK(hipMemcpy(dq, q, (size_t) n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dd, d, (size_t) m, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dl, hl, 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dm, &hm, sizeof(hm), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dr, hr, 12, hipMemcpyHostToDevice));
+    GactLds L = gact_lds_layout(gp.T);
+    size_t shmem = (size_t) L.wave_bytes * 4;
+    if (shmem > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gact_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem));
+    hipLaunchKernelGGL(gact_kernel, dim3(1), dim3(256), shmem, 0, dq, (uint64_t) 0, dl, dm, dr, dd, dl + 1,
+                       (uint64_t) 1, gp.T, gp.O, gp.W, dops, (uint64_t) 0, dr + 1, dr + 2, dc);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(hr, dr, 12, hipMemcpyDeviceToHost));
+    *n_ops = hr[1];
+    *score = hr[2];
+    if (hr[1] > 0) HIPCHK(hipMemcpy(ops, dops, (size_t) hr[1], hipMemcpyDeviceToHost));
+    (void) hipFree(dq); (void) hipFree(dd); (void) hipFree(dops); (void) hipFree(dl);
+    (void) hipFree(dm); (void) hipFree(dr); (void) hipFree(dc);
+    return 0;
+}

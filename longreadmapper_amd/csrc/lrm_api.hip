@@ -1,0 +1,455 @@
+// lrm_api.hip -- C-ABI glue of liblrm_accel.so (include/lrm_accel.h):
+// device image packing, upload/adopt, workspaces, host-buffer and device-buffer batch calls.
+// No CPU fallback anywhere: without a HIP device every batch entry point returns an error.
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+#include "lrm_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void lrm_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    lrm_set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
+
+extern "C" const char *lrm_last_error(void) { return g_err; }
+extern "C" int lrm_abi_version(void) { return LRM_ABI_VERSION; }
+
+extern "C" int lrm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static inline uint64_t align256(uint64_t x) { return (x + 255ull) & ~255ull; }
+
+static void blob_layout(uint64_t length, int hlen, int mta_len, LrmBlobHeader *h) {
+    memset(h, 0, sizeof(*h));
+    h->magic = LRM_BLOB_MAGIC;
+    h->version = LRM_ABI_VERSION;
+    h->length = length;
+    h->hlen = hlen;
+    h->mta_len = mta_len;
+    h->n_blocks = (length + LRM_OCC_ROWS - 1) / LRM_OCC_ROWS + 1;   // +1: rank(loc) may touch the block of L-1 only; spare block keeps gathers in bounds
+    h->lc_entries = 1ull << (2 * hlen);
+    h->sa_len = length;
+    h->con_len = length;
+    uint64_t off = sizeof(LrmBlobHeader);
+    h->off_occ = off;       off = align256(off + h->n_blocks * sizeof(LrmOccBlock));
+    h->off_lc = off;        off = align256(off + h->lc_entries * 16);
+    h->off_sa = off;        off = align256(off + h->sa_len * 8);
+    h->off_content = off;   off = align256(off + h->con_len + 1);
+    h->off_mta = off;       off = align256(off + (uint64_t) (mta_len > 0 ? mta_len : 1) * sizeof(LrmMtaDev));
+    h->total_bytes = off;
+}
+
+extern "C" uint64_t lrm_index_blob_bytes(uint64_t length, int hlen, int mta_len) {
+    LrmBlobHeader h;
+    blob_layout(length, hlen, mta_len, &h);
+    return h.total_bytes;
+}
+
+static inline int code_of(char c) {
+    switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
+}
+
+extern "C" int lrm_index_pack_blob(const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
+                                   const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len,
+                                   void *blob, uint64_t blob_bytes) {
+    if (!fmi || !lch || !sa || !content || !blob) { lrm_set_error("null argument"); return -1; }
+    const uint64_t L = fmi->length;
+    if (L < 2 || L >= (1ull << 40)) { lrm_set_error("text length %llu outside [2, 2^40)", (unsigned long long) L); return -1; }
+    if (con_len != L) { lrm_set_error("content length %llu != fm length %llu", (unsigned long long) con_len, (unsigned long long) L); return -1; }
+    if (sa->len < L) { lrm_set_error("suffix array has %llu rows, need %llu", (unsigned long long) sa->len, (unsigned long long) L); return -1; }
+    if (lch->hlen < 1 || lch->hlen > 15) { lrm_set_error("hlen %d outside [1,15] (lchash.c:75-77)", lch->hlen); return -1; }
+    if (lch->len != 2ull << (2 * lch->hlen)) { lrm_set_error("lc table length %llu != 2*4^hlen", (unsigned long long) lch->len); return -1; }
+    if (mta_len < 0 || (mta_len > 0 && !mta)) { lrm_set_error("bad mta"); return -1; }
+    LrmBlobHeader h;
+    blob_layout(L, lch->hlen, mta_len, &h);
+    if (blob_bytes < h.total_bytes) { lrm_set_error("blob buffer too small"); return -1; }
+    h.c4[0] = fmi->c[(unsigned char) 'A']; h.c4[1] = fmi->c[(unsigned char) 'C'];
+    h.c4[2] = fmi->c[(unsigned char) 'G']; h.c4[3] = fmi->c[(unsigned char) 'T'];
+    uint8_t *base = (uint8_t *) blob;
+    memset(base, 0, sizeof(LrmBlobHeader));
+
+    // occ blocks from the bwt; cross-checked against the reference's sampled O table
+    LrmOccBlock *occ = (LrmOccBlock *) (base + h.off_occ);
+    memset(occ, 0, h.n_blocks * sizeof(LrmOccBlock));
+    uint64_t run[4] = {0, 0, 0, 0};
+    uint64_t dollar = ~0ull;
+    const uint64_t ratio = (uint64_t) fmi->o_ratio;
+    for (uint64_t i = 0; i < L; ++i) {
+        if ((i & (LRM_OCC_ROWS - 1)) == 0) {
+            LrmOccBlock *b = &occ[i >> 7];
+            b->cnt[0] = run[0]; b->cnt[1] = run[1]; b->cnt[2] = run[2]; b->cnt[3] = run[3];
+        }
+        if (fmi->o && ratio > 0 && i % ratio == 0) {
+            const uint64_t *o = fmi->o + 4 * (i / ratio);
+            if (o[0] != run[0] || o[1] != run[1] || o[2] != run[2] || o[3] != run[3]) {
+                lrm_set_error("O table disagrees with bwt at row %llu", (unsigned long long) i);
+                return -1;
+            }
+        }
+        char ch = fmi->bwt[i];
+        int code = code_of(ch);
+        if (code < 0) {
+            if (ch == '$' && dollar == ~0ull) { dollar = i; code = 0; }
+            else { lrm_set_error("bwt row %llu holds byte 0x%02x (only upper-case ACGT and one '$' supported)", (unsigned long long) i, (unsigned) (unsigned char) ch); return -1; }
+        } else {
+            run[code]++;
+        }
+        occ[i >> 7].bits[(i & 127) >> 5] |= (uint64_t) code << (2 * (i & 31));
+    }
+    {   // spare block(s) after the last row carry the final counts
+        for (uint64_t b = (L + LRM_OCC_ROWS - 1) / LRM_OCC_ROWS; b < h.n_blocks; ++b) {
+            occ[b].cnt[0] = run[0]; occ[b].cnt[1] = run[1]; occ[b].cnt[2] = run[2]; occ[b].cnt[3] = run[3];
+        }
+    }
+    if (dollar == ~0ull) { lrm_set_error("bwt has no '$' row"); return -1; }
+    h.dollar_row = dollar;
+
+    // lc table, permuted to the LSB-first code
+    uint64_t *lc = (uint64_t *) (base + h.off_lc);
+    const int hl = lch->hlen;
+    const uint64_t ne = h.lc_entries;
+#pragma omp parallel for schedule(static)
+    for (uint64_t num = 0; num < ne; ++num) {
+        uint64_t code = 0, t = num;
+        for (int i = 0; i < hl; ++i) { code = (code << 2) | (t & 3); t >>= 2; }   // reverse the 2-bit groups
+        lc[2 * code] = lch->lc[2 * num];
+        lc[2 * code + 1] = lch->lc[2 * num + 1];
+    }
+
+    uint64_t *sav = (uint64_t *) (base + h.off_sa);
+#pragma omp parallel for schedule(static)
+    for (uint64_t i = 0; i < L; ++i)
+        sav[i] = ((uint64_t) sa->mem[i].high << 32) | (uint64_t) sa->mem[i].low;   // sa_use.h:27-29
+
+    memcpy(base + h.off_content, content, L);
+    base[h.off_content + L] = 0;
+    LrmMtaDev *md = (LrmMtaDev *) (base + h.off_mta);
+    for (int i = 0; i < mta_len; ++i) { md[i].offset = mta[i].offset; md[i].seq_len = (uint64_t) mta[i].seq_len; }
+    memcpy(base, &h, sizeof(h));
+    return 0;
+}
+
+static int make_handle(lrm_index **out, void *d_blob, uint64_t bytes, int device, int owns, const LrmBlobHeader &h) {
+    if (h.magic != LRM_BLOB_MAGIC || h.version != LRM_ABI_VERSION) { lrm_set_error("not an lrm index image (magic/version)"); return -1; }
+    if (h.total_bytes > bytes) { lrm_set_error("index image truncated"); return -1; }
+    lrm_index *ix = new (std::nothrow) lrm_index;
+    if (!ix) { lrm_set_error("out of memory"); return -1; }
+    ix->d_blob = d_blob; ix->blob_bytes = bytes; ix->owns_blob = owns; ix->device = device; ix->hdr = h;
+    uint8_t *b = (uint8_t *) d_blob;
+    ix->view.occ = (const LrmOccBlock *) (b + h.off_occ);
+    ix->view.lc = (const uint64_t *) (b + h.off_lc);
+    ix->view.sa = (const uint64_t *) (b + h.off_sa);
+    ix->view.content = (const char *) (b + h.off_content);
+    ix->view.mta = (const LrmMtaDev *) (b + h.off_mta);
+    ix->view.length = h.length; ix->view.dollar_row = h.dollar_row;
+    ix->view.sa_len = h.sa_len; ix->view.con_len = h.con_len;
+    for (int i = 0; i < 4; ++i) ix->view.c4[i] = h.c4[i];
+    ix->view.hlen = h.hlen; ix->view.mta_len = h.mta_len;
+    *out = ix;
+    return 0;
+}
+
+static int require_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        lrm_set_error("no HIP device available (%s): liblrm_accel has no CPU fallback", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+        return -1;
+    }
+    if (device < 0 || device >= n) { lrm_set_error("device %d out of range (have %d)", device, n); return -1; }
+    HIPCHK(hipSetDevice(device));
+    return 0;
+}
+
+extern "C" int lrm_index_upload_blob(lrm_index **out, const void *blob, uint64_t blob_bytes, int device) {
+    if (!out || !blob || blob_bytes < sizeof(LrmBlobHeader)) { lrm_set_error("bad blob"); return -1; }
+    if (require_device(device)) return -1;
+    LrmBlobHeader h;
+    memcpy(&h, blob, sizeof(h));
+    void *d = nullptr;
+    HIPCHK(hipMalloc(&d, blob_bytes));
+    if (hipMemcpy(d, blob, blob_bytes, hipMemcpyHostToDevice) != hipSuccess) { (void) hipFree(d); lrm_set_error("index upload failed"); return -1; }
+    if (make_handle(out, d, blob_bytes, device, 1, h)) { (void) hipFree(d); return -1; }
+    return 0;
+}
+
+extern "C" int lrm_index_adopt_device(lrm_index **out, void *d_blob, uint64_t blob_bytes, int device) {
+    if (!out || !d_blob || blob_bytes < sizeof(LrmBlobHeader)) { lrm_set_error("bad blob"); return -1; }
+    if (require_device(device)) return -1;
+    LrmBlobHeader h;
+    HIPCHK(hipMemcpy(&h, d_blob, sizeof(h), hipMemcpyDeviceToHost));
+    return make_handle(out, d_blob, blob_bytes, device, 0, h);
+}
+
+extern "C" int lrm_index_upload(lrm_index **out, const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
+                                const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len, int device) {
+    if (!out || !fmi || !lch) { lrm_set_error("null argument"); return -1; }
+    if (require_device(device)) return -1;
+    uint64_t bytes = lrm_index_blob_bytes(fmi->length, lch->hlen, mta_len);
+    void *blob = malloc(bytes);
+    if (!blob) { lrm_set_error("out of host memory for a %llu-byte index image", (unsigned long long) bytes); return -1; }
+    int rc = lrm_index_pack_blob(fmi, lch, sa, content, con_len, mta, mta_len, blob, bytes);
+    if (rc == 0) rc = lrm_index_upload_blob(out, blob, bytes, device);
+    free(blob);
+    return rc;
+}
+
+struct HostCache { lrm_workspace *ws; };
+static thread_local HostCache g_cache = {nullptr};
+
+extern "C" void lrm_index_free(lrm_index *idx) {
+    if (!idx) return;
+    if (g_cache.ws && g_cache.ws->idx == idx) { lrm_workspace_free(g_cache.ws); g_cache.ws = nullptr; }
+    if (idx->owns_blob && idx->d_blob) { (void) hipSetDevice(idx->device); (void) hipFree(idx->d_blob); }
+    delete idx;
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------
+extern "C" void lrm_workspace_free(lrm_workspace *ws) {
+    if (!ws) return;
+    (void) hipSetDevice(ws->device);
+    (void) hipFree(ws->d_reads2); (void) hipFree(ws->d_rec); (void) hipFree(ws->d_phase); (void) hipFree(ws->d_decided);
+    (void) hipFree(ws->d_ovf_items); (void) hipFree(ws->d_ovf_tables); (void) hipFree(ws->d_counters);
+    delete ws;
+}
+
+extern "C" uint64_t lrm_workspace_bytes(const lrm_workspace *ws) { return ws ? ws->bytes : 0; }
+
+extern "C" int lrm_workspace_create(lrm_workspace **out, lrm_index *idx, uint64_t n_max, uint32_t max_len,
+                                    uint32_t seed_len, uint32_t thres) {
+    if (!out || !idx) { lrm_set_error("null argument"); return -1; }
+    if (seed_len < 1 || seed_len > 32) { lrm_set_error("seed_len %u outside [1,32]", seed_len); return -1; }
+    if (thres >= (1u << 24)) { lrm_set_error("thres %u >= 2^24 unsupported", thres); return -1; }
+    if (n_max == 0) n_max = 1;
+    if (require_device(idx->device)) return -1;
+    lrm_workspace *ws = new (std::nothrow) lrm_workspace;
+    if (!ws) { lrm_set_error("out of memory"); return -1; }
+    memset(ws, 0, sizeof(*ws));
+    ws->idx = idx; ws->device = idx->device; ws->n_max = n_max; ws->max_len = max_len;
+    ws->seed_len = seed_len; ws->thres = thres;
+    ws->P = seed_len + 1;
+    uint32_t jl = max_len > seed_len ? max_len - seed_len : 0;
+    ws->cap_q = (jl + ws->P - 1) / ws->P;
+    if (ws->cap_q == 0) ws->cap_q = 1;
+    ws->words_per_read = (uint64_t) max_len / 32 + 2;
+    ws->ovf_slots = 32;
+    uint64_t need = 2ull * ws->cap_q * (uint64_t) (thres > 1 ? thres - 1 : 1);
+    uint64_t cap = 1024;
+    while (cap < need && cap < (1ull << 22)) cap <<= 1;
+    ws->ovf_cap = cap;
+    struct { void **p; uint64_t bytes; } allocs[] = {
+        {(void **) &ws->d_reads2, n_max * ws->words_per_read * 8},
+        {(void **) &ws->d_rec, n_max * (uint64_t) ws->P * ws->cap_q * 8},
+        {(void **) &ws->d_phase, n_max * (uint64_t) ws->P * sizeof(LrmPhaseRes)},
+        {(void **) &ws->d_decided, n_max},
+        {(void **) &ws->d_ovf_items, n_max * (uint64_t) ws->P * 8},
+        {(void **) &ws->d_ovf_tables, ws->ovf_slots * ws->ovf_cap * 32},
+        {(void **) &ws->d_counters, sizeof(LrmDevCounters)},
+    };
+    for (auto &a : allocs) {
+        if (hipMalloc(a.p, a.bytes) != hipSuccess) {
+            lrm_set_error("hipMalloc of %llu workspace bytes failed", (unsigned long long) a.bytes);
+            lrm_workspace_free(ws);
+            return -1;
+        }
+        ws->bytes += a.bytes;
+    }
+    if (hipMemset(ws->d_counters, 0, sizeof(LrmDevCounters)) != hipSuccess) { lrm_workspace_free(ws); lrm_set_error("memset failed"); return -1; }
+    *out = ws;
+    return 0;
+}
+
+static int check_ws(lrm_workspace *ws, lrm_index *idx, uint64_t n, uint32_t max_len, uint32_t seed_len, uint32_t thres) {
+    if (!ws || ws->idx != idx) { lrm_set_error("workspace does not belong to this index"); return -1; }
+    if (n > ws->n_max || max_len > ws->max_len || seed_len != ws->seed_len || thres > ws->thres) {
+        lrm_set_error("workspace too small: have n=%llu len=%u seed=%u thres=%u, need n=%llu len=%u seed=%u thres=%u",
+                      (unsigned long long) ws->n_max, ws->max_len, ws->seed_len, ws->thres,
+                      (unsigned long long) n, max_len, seed_len, thres);
+        return -1;
+    }
+    return 0;
+}
+
+extern "C" int lrm_seed_batch_dev(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint64_t stride,
+                                  const uint32_t *d_lens, uint64_t n, uint32_t max_len, lrm_params p,
+                                  lrm_entry *d_best, void *stream) {
+    if (!idx || !d_reads || !d_lens || !d_best) { lrm_set_error("null argument"); return -1; }
+    if (check_ws(ws, idx, n, max_len, p.seed_len, p.thres)) return -1;
+    if (stride < max_len) { lrm_set_error("stride %llu < max_len %u", (unsigned long long) stride, max_len); return -1; }
+    HIPCHK(hipSetDevice(idx->device));
+    return lrm_launch_seed(idx, ws, d_reads, stride, d_lens, n, max_len, p.seed_len, p.thres, d_best, stream);
+}
+
+extern "C" int lrm_extend_batch_dev(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint64_t stride,
+                                    const uint32_t *d_lens, uint64_t n, uint32_t max_len, const lrm_entry *d_best,
+                                    lrm_gact_params gp, uint8_t *d_store, uint64_t store_stride, int32_t *d_n_ops,
+                                    int32_t *d_score, lrm_seq_meta *d_meta, int32_t *d_meta_r, void *stream) {
+    if (!idx || !ws || !d_reads || !d_lens || !d_best || !d_store || !d_n_ops || !d_score || !d_meta || !d_meta_r) {
+        lrm_set_error("null argument");
+        return -1;
+    }
+    if (ws->idx != idx) { lrm_set_error("workspace does not belong to this index"); return -1; }
+    HIPCHK(hipSetDevice(idx->device));
+    return lrm_launch_extend(idx, ws, d_reads, stride, d_lens, n, max_len, d_best, gp, d_store, store_stride,
+                             d_n_ops, d_score, d_meta, d_meta_r, stream);
+}
+
+extern "C" int lrm_workspace_stats(lrm_workspace *ws, lrm_stats *out, void *stream) {
+    if (!ws || !out) { lrm_set_error("null argument"); return -1; }
+    HIPCHK(hipSetDevice(ws->device));
+    LrmDevCounters c;
+    HIPCHK(hipMemcpyAsync(&c, ws->d_counters, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t) stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t) stream));
+    out->vote_overflow_items = c.overflow_n[0] + c.overflow_n[1];
+    out->reads_decided_phase0 = c.decided_phase0;
+    out->gact_tiles = c.gact_tiles;
+    if (c.error_flags & 1ull) { lrm_set_error("vote fallback table capacity exceeded: results of some phases are invalid"); return -2; }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-buffer entry points (drop-in boundary): stage through device buffers
+// ------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void) hipFree(p); }
+    int alloc(uint64_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? 0 : -1; }
+};
+
+static int get_cached_ws(lrm_index *idx, uint64_t n, uint32_t max_len, uint32_t seed_len, uint32_t thres, lrm_workspace **out) {
+    lrm_workspace *ws = g_cache.ws;
+    if (ws && ws->idx == idx && n <= ws->n_max && max_len <= ws->max_len && seed_len == ws->seed_len && thres <= ws->thres) {
+        *out = ws;
+        return 0;
+    }
+    if (ws) { lrm_workspace_free(ws); g_cache.ws = nullptr; }
+    if (lrm_workspace_create(&ws, idx, n, max_len, seed_len, thres)) return -1;
+    g_cache.ws = ws;
+    *out = ws;
+    return 0;
+}
+
+static uint32_t max_of(const uint32_t *lens, uint64_t n) {
+    uint32_t m = 0;
+    for (uint64_t i = 0; i < n; ++i) m = lens[i] > m ? lens[i] : m;
+    return m;
+}
+
+extern "C" int lrm_seed_batch(lrm_index *idx, const char *reads_buf, uint64_t stride, const uint32_t *lens,
+                              uint64_t n, lrm_params p, lrm_entry *best_out) {
+    if (!idx || !reads_buf || !lens || !best_out) { lrm_set_error("null argument"); return -1; }
+    if (n == 0) return 0;
+    if (require_device(idx->device)) return -1;
+    uint32_t max_len = max_of(lens, n);
+    if (stride < max_len) { lrm_set_error("stride < longest read"); return -1; }
+    lrm_workspace *ws;
+    if (get_cached_ws(idx, n, max_len, p.seed_len, p.thres, &ws)) return -1;
+    DevBuf d_reads, d_lens, d_best;
+    if (d_reads.alloc(n * stride) || d_lens.alloc(n * 4) || d_best.alloc(n * sizeof(lrm_entry))) { lrm_set_error("device allocation failed"); return -1; }
+    HIPCHK(hipMemcpy(d_reads.p, reads_buf, n * stride, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_lens.p, lens, n * 4, hipMemcpyHostToDevice));
+    if (lrm_launch_seed(idx, ws, (const char *) d_reads.p, stride, (const uint32_t *) d_lens.p, n, max_len, p.seed_len,
+                        p.thres, (lrm_entry *) d_best.p, nullptr)) return -1;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(best_out, d_best.p, n * sizeof(lrm_entry), hipMemcpyDeviceToHost));
+    lrm_stats st;
+    if (lrm_workspace_stats(ws, &st, nullptr)) return -1;
+    return 0;
+}
+
+extern "C" int lrm_extend_batch(lrm_index *idx, char *reads_buf, uint64_t stride, const uint32_t *lens, uint64_t n,
+                                const lrm_entry *best, lrm_gact_params gp, lrm_cigar *cig_out, uint8_t *store_mem,
+                                uint64_t store_stride, int *score_out, lrm_seq_meta *meta_out, int *meta_r_out) {
+    if (!idx || !reads_buf || !lens || !best || !cig_out || !store_mem || !score_out || !meta_out || !meta_r_out) {
+        lrm_set_error("null argument");
+        return -1;
+    }
+    if (n == 0) return 0;
+    if (require_device(idx->device)) return -1;
+    uint32_t max_len = max_of(lens, n);
+    if (stride < max_len) { lrm_set_error("stride < longest read"); return -1; }
+    lrm_workspace *ws = g_cache.ws;
+    if (!ws || ws->idx != idx) {
+        if (get_cached_ws(idx, n, max_len, 20, 300, &ws)) return -1;   // extend only needs the counters block
+    }
+    DevBuf d_reads, d_lens, d_best, d_store, d_nops, d_score, d_meta, d_mr;
+    if (d_reads.alloc(n * stride) || d_lens.alloc(n * 4) || d_best.alloc(n * sizeof(lrm_entry)) ||
+        d_store.alloc(n * store_stride) || d_nops.alloc(n * 4) || d_score.alloc(n * 4) ||
+        d_meta.alloc(n * sizeof(lrm_seq_meta)) || d_mr.alloc(n * 4)) { lrm_set_error("device allocation failed"); return -1; }
+    HIPCHK(hipMemcpy(d_reads.p, reads_buf, n * stride, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_lens.p, lens, n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_best.p, best, n * sizeof(lrm_entry), hipMemcpyHostToDevice));
+    if (lrm_launch_extend(idx, ws, (char *) d_reads.p, stride, (const uint32_t *) d_lens.p, n, max_len,
+                          (const lrm_entry *) d_best.p, gp, (uint8_t *) d_store.p, store_stride, (int32_t *) d_nops.p,
+                          (int32_t *) d_score.p, (lrm_seq_meta *) d_meta.p, (int32_t *) d_mr.p, nullptr)) return -1;
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<int32_t> nops(n);
+    HIPCHK(hipMemcpy(reads_buf, d_reads.p, n * stride, hipMemcpyDeviceToHost));      // rev-comped reads travel back
+    HIPCHK(hipMemcpy(store_mem, d_store.p, n * store_stride, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nops.data(), d_nops.p, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(score_out, d_score.p, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(meta_out, d_meta.p, n * sizeof(lrm_seq_meta), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(meta_r_out, d_mr.p, n * 4, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; ++i) {                                              // alnmain.c:322-325, mutils.c:99-104
+        cig_out[i].cigar = store_mem + i * store_stride;
+        cig_out[i].n_cigar_op = nops[i];
+        cig_out[i].score = score_out[i];
+    }
+    return 0;
+}
+
+extern "C" void lrm_result_flags(const int *score, const int *meta_r, const lrm_seq_meta *meta, uint64_t n,
+                                 int *flag_out, int *mapq_out, int *valid_out) {
+    for (uint64_t i = 0; i < n; ++i) {                     // alnmain.c:460-474
+        int flag = 0, mapq = 255, valid = score[i] >= 0;
+        if (meta_r[i] == 0 || score[i] == -1) { valid = 0; flag += 0x4; mapq = 0; }
+        else if (meta[i].strand == 1) flag += 16;
+        flag_out[i] = flag; mapq_out[i] = mapq; valid_out[i] = valid;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// debug taps (tests only)
+// ------------------------------------------------------------------------------------------
+extern "C" int lrm_debug_seed_search(lrm_index *idx, const char *read, uint32_t len, uint32_t seed_len, uint32_t thres,
+                                     int32_t *j_out, uint64_t *rr_out, uint64_t *k_out, uint64_t *l_out, uint64_t cap,
+                                     uint64_t *n_out) {
+    (void) thres;
+    if (!idx || !read || !n_out) { lrm_set_error("null argument"); return -1; }
+    if (seed_len < 1 || seed_len > 32) { lrm_set_error("seed_len %u outside [1,32]", seed_len); return -1; }
+    if (require_device(idx->device)) return -1;
+    uint64_t words = (uint64_t) len / 32 + 2;
+    DevBuf d_read, d_r2, d_j, d_rr, d_k, d_l;
+    if (d_read.alloc(len + 1) || d_r2.alloc((words + 1) * 8) || d_j.alloc(cap * 4) || d_rr.alloc(cap * 8) ||
+        d_k.alloc(cap * 8) || d_l.alloc(cap * 8)) { lrm_set_error("device allocation failed"); return -1; }
+    HIPCHK(hipMemcpy(d_read.p, read, len, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(d_j.p, 0xff, cap * 4));
+    int cap_q = lrm_launch_debug_seed(idx, (const char *) d_read.p, len, seed_len, (uint64_t *) d_r2.p, words,
+                                      (int32_t *) d_j.p, (uint64_t *) d_rr.p, (uint64_t *) d_k.p, (uint64_t *) d_l.p,
+                                      cap, nullptr);
+    if (cap_q < 0) return -1;
+    HIPCHK(hipDeviceSynchronize());
+    uint64_t total = (uint64_t) cap_q * (seed_len + 1);
+    HIPCHK(hipMemcpy(j_out, d_j.p, total * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rr_out, d_rr.p, total * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(k_out, d_k.p, total * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(l_out, d_l.p, total * 8, hipMemcpyDeviceToHost));
+    *n_out = total;
+    return cap_q;
+}

@@ -1,0 +1,123 @@
+// lrm_internal.h -- device image layout + internal declarations of liblrm_accel.so
+//
+// Device image ("blob"), designed for gfx950 gathers rather than copied from the
+// reference's in-memory arrays:
+//
+//   [BlobHeader 256 B]
+//   [occ blocks]   one 64-byte block per 128 BWT rows:
+//                    u64 cnt[4]   #A,#C,#G,#T in bwt[0 .. 128*blk)   ('$' not counted)
+//                    u64 bits[4]  the 128 rows, 2 bits each, row r at word r/32, bit 2*(r%32)
+//                  -> one rank query == ONE aligned 64-B gather (the reference layout,
+//                     fmidx.c:277-293, needs an 8-B o[] read plus a <=32-B bwt scan in a
+//                     different array).  The '$' row is stored as code 0 and compensated
+//                     through header.dollar_row.
+//   [lc table]     4^hlen entries {u64 k, u64 l}, indexed by the LSB-first 2-bit code of the
+//                  hlen-mer (base i at bits 2i..2i+1) so the kernel extracts the index as one
+//                  bit field of the packed read.  (reference: first base most significant,
+//                  lchash.c:36-49; the packer permutes.)
+//   [sa]           u64 per row (values of sa_access, fmidx.c:18-33)
+//   [content]      the .cat text, 1 byte per base (GACT target side)
+//   [mta]          {u64 offset, u64 seq_len} per sequence (accaln.h:67-71 without names)
+//
+// All sections are 256-byte aligned.
+#pragma once
+#include <stdint.h>
+#include "../../include/lrm_accel.h"
+
+#define LRM_BLOB_MAGIC 0x4c524d424c4f4231ull   // "LRMBLOB1"
+#define LRM_OCC_ROWS 128
+
+struct LrmOccBlock {
+    uint64_t cnt[4];
+    uint64_t bits[4];
+};
+static_assert(sizeof(LrmOccBlock) == 64, "occ block must be one 64-B line");
+
+struct LrmMtaDev { uint64_t offset, seq_len; };
+
+struct LrmBlobHeader {
+    uint64_t magic, version;
+    uint64_t length;        // L = bwt rows = text bytes
+    uint64_t c4[4];         // C[] for A,C,G,T  (fmidx.c:101-125)
+    uint64_t dollar_row;    // row whose bwt char is '$'
+    uint64_t n_blocks;
+    uint64_t lc_entries;    // 4^hlen
+    uint64_t sa_len, con_len;
+    uint64_t off_occ, off_lc, off_sa, off_content, off_mta;
+    uint64_t total_bytes;
+    int32_t hlen, mta_len;
+    uint64_t reserved[13];
+};
+static_assert(sizeof(LrmBlobHeader) == 256, "header is 256 B");
+
+// What kernels receive by value.
+struct LrmIndexView {
+    const LrmOccBlock *occ;
+    const uint64_t *lc;       // pairs
+    const uint64_t *sa;
+    const char *content;
+    const LrmMtaDev *mta;
+    uint64_t length, dollar_row, sa_len, con_len;
+    uint64_t c4[4];
+    int32_t hlen, mta_len;
+};
+
+struct lrm_index {
+    void *d_blob;
+    uint64_t blob_bytes;
+    int owns_blob;
+    int device;
+    LrmBlobHeader hdr;
+    LrmIndexView view;
+};
+
+// Per-(read,phase) vote result written by the vote kernels.
+struct LrmPhaseRes {
+    uint64_t key1, val1, bucket1;
+    uint64_t key2, val2, bucket2;
+};
+
+// Device counters block (one per workspace).
+struct LrmDevCounters {
+    unsigned long long overflow_n[2];    // per launch round: (read,phase) items in the overflow list
+    unsigned long long overflow_done[2]; // per launch round: work-queue head of the fallback kernel
+    unsigned long long decided_phase0;
+    unsigned long long gact_tiles;
+    unsigned long long error_flags;      // bit0: fallback table capacity exceeded
+    unsigned long long pad;
+};
+
+struct lrm_workspace {
+    lrm_index *idx;
+    int device;
+    uint64_t n_max;
+    uint32_t max_len, seed_len, thres;
+    uint32_t P;              // seed_len + 1 phases
+    uint32_t cap_q;          // seeds per phase capacity
+    uint64_t words_per_read; // u64 words of the 2-bit packed read (+1 guard)
+    uint64_t bytes;
+    // device buffers
+    uint64_t *d_reads2;      // packed reads
+    uint64_t *d_rec;         // per-seed records: n_max * P * cap_q
+    LrmPhaseRes *d_phase;    // n_max * P
+    uint8_t *d_decided;      // n_max
+    uint64_t *d_ovf_items;   // overflow items (read*P+iter): round 0 at [0,n_max), round 1 after
+    void *d_ovf_tables;      // fallback vote tables (global memory)
+    uint64_t ovf_slots, ovf_cap;   // concurrent fallback blocks, entries per table
+    LrmDevCounters *d_counters;
+};
+
+void lrm_set_error(const char *fmt, ...);
+
+// launchers implemented in the .hip files (all asynchronous on `stream`)
+int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint64_t stride,
+                    const uint32_t *d_lens, uint64_t n, uint32_t max_len, uint32_t seed_len,
+                    uint32_t thres, lrm_entry *d_best, void *stream);
+int lrm_launch_extend(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint64_t stride,
+                      const uint32_t *d_lens, uint64_t n, uint32_t max_len,
+                      const lrm_entry *d_best, lrm_gact_params gp, uint8_t *d_store,
+                      uint64_t store_stride, int32_t *d_n_ops, int32_t *d_score,
+                      lrm_seq_meta *d_meta, int32_t *d_meta_r, void *stream);
+int lrm_launch_debug_seed(lrm_index *idx, const char *d_read, uint32_t len, uint32_t seed_len,
+                          uint64_t *d_reads2, uint64_t words, int32_t *d_j, uint64_t *d_rr,
+                          uint64_t *d_k, uint64_t *d_l, uint64_t cap, void *stream);

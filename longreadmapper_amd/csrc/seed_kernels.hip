@@ -1,0 +1,610 @@
+// seed_kernels.hip -- gfx950 kernels for PART 1 of the accaln hot path
+// (reference: alnmain.c:333-405; lchash.c:12-16,36-49,89-104; fmidx.c:18-33,277-313;
+//  histo.c:26-56,84-96).  Integer gathers + LDS voting; no MFMA (nothing here is a
+// contraction).
+//
+// Decomposition (MI355X-first, not the reference's per-read loop nest):
+//   pack2bit      reads (1 B/base) -> 2 bit/base stream, so a seed is ONE bit-field window
+//   seed_search   one lane per seed: lc lookup + FM backward extension        (K1, HBM gathers)
+//   vote          one wavefront per (read, phase): SA gather + LDS vote table  (K2)
+//   vote_fallback same, global-memory table, for phases that overflow the LDS table
+//   decide        one lane per read: the phase state machine of alnmain.c:371-403
+//
+// The reference evaluates phases one after another and stops at the first phase whose
+// top-2 vote passes 0.6.  Phases are independent computations, so evaluating them
+// speculatively and replaying the decisions in order is exact.  To avoid 21x waste on
+// clean reads the host launches phase 0 first and phases 1..s only for undecided reads.
+#include <hip/hip_runtime.h>
+#include "lrm_internal.h"
+
+#define VOTE_SLOTS 256           // LDS vote-table slots per wavefront
+#define VOTE_MAX_PROBE 48
+#define EMPTY64 0xFFFFFFFFFFFFFFFFull
+
+// A/a=0 C/c=1 G/g=2 T/t=3 ; other bytes are fenced (UB in the reference, lchash.c:38-44)
+__device__ __forceinline__ uint32_t base_code(uint32_t c) { return ((c >> 1) ^ (c >> 2)) & 3u; }
+
+// ----------------------------------------------------------------------------------------
+// pack2bit: one thread per output byte (4 bases).  Bases past the read end pack as 0.
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack2bit_kernel(const char *__restrict__ reads, uint64_t stride,
+                                                       const uint32_t *__restrict__ lens,
+                                                       uint8_t *__restrict__ out, uint64_t bytes_per_read,
+                                                       uint32_t chunks_per_read, uint64_t n) {
+    uint64_t read = blockIdx.x / chunks_per_read;
+    uint32_t chunk = blockIdx.x % chunks_per_read;
+    if (read >= n) return;
+    uint64_t ob = (uint64_t) chunk * 256 + threadIdx.x;
+    if (ob >= bytes_per_read) return;
+    uint32_t len = lens[read];
+    const uint8_t *r = (const uint8_t *) reads + read * stride;
+    uint64_t p = ob * 4;
+    uint32_t v = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        uint32_t code = (p + t < len) ? base_code(r[p + t]) : 0u;
+        v |= code << (2 * t);
+    }
+    out[read * bytes_per_read + ob] = (uint8_t) v;
+}
+
+// ----------------------------------------------------------------------------------------
+// FM rank on the 64-byte occ blocks
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t match_count(uint64_t w, uint64_t pat, uint32_t nrows) {
+    // rows whose 2-bit symbol equals the pattern, among the first nrows (0..32) rows of w
+    uint64_t x = w ^ pat;
+    uint64_t m = ~(x | (x >> 1)) & 0x5555555555555555ull;
+    uint64_t mask = nrows >= 32 ? ~0ull : ((1ull << (2 * nrows)) - 1ull);
+    return (uint32_t) __popcll(m & mask);
+}
+
+__device__ __forceinline__ uint64_t block_rank(const LrmIndexView &ix, uint64_t blk, const uint64_t cnt_c,
+                                               const uint64_t b0, const uint64_t b1, const uint64_t b2,
+                                               const uint64_t b3, uint32_t c, uint32_t r) {
+    // # of symbol c in rows [128*blk, 128*blk + r]  (r inclusive, 0..127) + block prefix
+    uint64_t pat = (uint64_t) c * 0x5555555555555555ull;
+    uint32_t n = r + 1;
+    uint32_t cnt = match_count(b0, pat, n);
+    cnt += match_count(b1, pat, n > 32 ? n - 32 : 0);
+    cnt += match_count(b2, pat, n > 64 ? n - 64 : 0);
+    cnt += match_count(b3, pat, n > 96 ? n - 96 : 0);
+    uint64_t res = cnt_c + cnt;
+    // the '$' row is stored as code 0; the reference never counts it (fmidx.c:290 compares bytes)
+    if (c == 0 && (ix.dollar_row >> 7) == blk && (uint32_t) (ix.dollar_row & 127) <= r) res -= 1;
+    return res;
+}
+
+struct OccLine { uint64_t cnt, b0, b1, b2, b3; };
+
+__device__ __forceinline__ OccLine load_occ(const LrmIndexView &ix, uint64_t blk, uint32_t c) {
+    const LrmOccBlock *b = ix.occ + blk;
+    OccLine o;
+    o.cnt = b->cnt[c];
+    const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(&b->bits[0]);
+    const ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(&b->bits[2]);
+    o.b0 = v0.x; o.b1 = v0.y; o.b2 = v1.x; o.b3 = v1.y;
+    return o;
+}
+
+// rank(c, loc) = # of c in bwt[0..loc]  == _occ_access (fmidx.c:277-293)
+__device__ __forceinline__ void rank2(const LrmIndexView &ix, uint32_t c, uint64_t loc_a, uint64_t loc_b,
+                                      uint64_t &ra, uint64_t &rb) {
+    uint64_t blk_a = loc_a >> 7, blk_b = loc_b >> 7;
+    OccLine ob = load_occ(ix, blk_b, c);
+    rb = block_rank(ix, blk_b, ob.cnt, ob.b0, ob.b1, ob.b2, ob.b3, c, (uint32_t) (loc_b & 127));
+    if (blk_a == blk_b) {           // small intervals: one 64-B line serves both ranks
+        ra = block_rank(ix, blk_a, ob.cnt, ob.b0, ob.b1, ob.b2, ob.b3, c, (uint32_t) (loc_a & 127));
+    } else {
+        OccLine oa = load_occ(ix, blk_a, c);
+        ra = block_rank(ix, blk_a, oa.cnt, oa.b0, oa.b1, oa.b2, oa.b3, c, (uint32_t) (loc_a & 127));
+    }
+}
+
+// lc_aln (lchash.c:89-104) + fmi_aln (fmidx.c:295-313) on the packed read.
+// win: bases j.. of the read, 2 bits each, LSB first.  Returns rr; k,l as the reference
+// leaves them (also on failure).
+__device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t win, int seed_len,
+                                             uint64_t &k, uint64_t &l) {
+    int left = seed_len - ix.hlen;
+    if (left >= 0) {
+        uint64_t code = (win >> (2 * left)) & ((1ull << (2 * ix.hlen)) - 1ull);
+        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(ix.lc + 2 * code);
+        k = e.x;
+        l = e.y;
+    } else {
+        k = 1;
+        l = ix.length - 1;
+    }
+    if (k == 0 && l == 0) return 0;
+    for (int i = left - 1; i >= 0; --i) {
+        uint32_t c = (uint32_t) (win >> (2 * i)) & 3u;
+        uint64_t ra, rb;
+        rank2(ix, c, k - 1, l, ra, rb);
+        k = ix.c4[c] + ra + 1;
+        l = ix.c4[c] + rb;
+        if (k > l) break;
+    }
+    return k > l ? 0 : l - k + 1;
+}
+
+__device__ __forceinline__ uint64_t read_window(const uint64_t *__restrict__ words, uint32_t j) {
+    uint32_t wi = j >> 5, sh = (j & 31) * 2;
+    uint64_t w0 = words[wi], w1 = words[wi + 1];
+    return sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+}
+
+// ----------------------------------------------------------------------------------------
+// K1 seed_search: one lane per seed.  Work items of a read are (q, iter) with iter fastest,
+// so neighbouring lanes touch neighbouring read positions j = iter + q*P.
+// rec[read][iter][q] = k | rr<<40  when 0 < rr < thres, else 0.
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const uint64_t *__restrict__ reads2,
+                                                          uint64_t words_per_read,
+                                                          const uint32_t *__restrict__ lens,
+                                                          const uint8_t *__restrict__ decided, uint64_t n,
+                                                          int seed_len, uint32_t thres, int phase_lo, int phase_hi,
+                                                          uint32_t cap_q, uint32_t blocks_per_read,
+                                                          uint64_t *__restrict__ rec) {
+    uint64_t read = blockIdx.x / blocks_per_read;
+    uint32_t chunk = blockIdx.x % blocks_per_read;
+    if (read >= n) return;
+    if (decided && decided[read]) return;
+    const int P = seed_len + 1;
+    const int np = phase_hi - phase_lo + 1;
+    uint32_t item = chunk * 256 + threadIdx.x;
+    uint32_t q = item / (uint32_t) np;
+    int iter = phase_lo + (int) (item % (uint32_t) np);
+    if (q >= cap_q) return;
+    uint32_t len = lens[read];
+    uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;   // alnmain.c:353 (fenced for len<s)
+    uint64_t j = (uint64_t) iter + (uint64_t) q * (uint64_t) P;
+    uint64_t *out = rec + (read * (uint64_t) P + (uint64_t) iter) * cap_q + q;
+    if (j >= jl) { *out = 0; return; }
+    uint64_t win = read_window(reads2 + read * words_per_read, (uint32_t) j);
+    uint64_t k, l;
+    uint64_t rr = seed_one(ix, win, seed_len, k, l);
+    *out = (rr > 0 && rr < (uint64_t) thres) ? (k | (rr << 40)) : 0ull;
+}
+
+// debug tap: full (j, rr, k, l) per seed of one read, in (iter, q) order
+__global__ __launch_bounds__(256) void seed_search_debug_kernel(LrmIndexView ix, const uint64_t *__restrict__ words,
+                                                                uint32_t len, int seed_len, uint32_t cap_q,
+                                                                int32_t *j_out, uint64_t *rr_out, uint64_t *k_out,
+                                                                uint64_t *l_out) {
+    const int P = seed_len + 1;
+    uint32_t item = blockIdx.x * 256 + threadIdx.x;
+    uint32_t iter = item / cap_q, q = item % cap_q;
+    if (iter >= (uint32_t) P) return;
+    uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;
+    uint64_t j = (uint64_t) iter + (uint64_t) q * (uint64_t) P;
+    uint64_t o = (uint64_t) iter * cap_q + q;
+    if (j >= jl) { j_out[o] = -1; return; }
+    uint64_t win = read_window(words, (uint32_t) j);
+    uint64_t k, l;
+    uint64_t rr = seed_one(ix, win, seed_len, k, l);
+    j_out[o] = (int32_t) j; rr_out[o] = rr; k_out[o] = k; l_out[o] = l;
+}
+
+// ----------------------------------------------------------------------------------------
+// K2 vote: one wavefront per (read, phase).
+// histo_add / histo_find_2_max (histo.c:42-56, 84-96) order entries by insertion; the
+// stable top-2 is "val descending, first-seen ascending".  First-seen order of a bucket is
+// the order of (seed ordinal q, SA offset t) of its first hit, which is intrinsic to the hit,
+// so the table can be filled in any order: every slot keeps count, min key, min (q,t).
+// ----------------------------------------------------------------------------------------
+struct Cand { uint32_t val; uint32_t slot; uint64_t seq; };
+
+__device__ __forceinline__ bool better(const Cand &a, const Cand &b) {
+    return a.val > b.val || (a.val == b.val && a.seq < b.seq);
+}
+
+__device__ __forceinline__ Cand shfl_xor_cand(const Cand &c, int m) {
+    Cand o;
+    o.val = __shfl_xor(c.val, m);
+    o.slot = __shfl_xor(c.slot, m);
+    uint32_t lo = __shfl_xor((uint32_t) c.seq, m), hi = __shfl_xor((uint32_t) (c.seq >> 32), m);
+    o.seq = ((uint64_t) hi << 32) | lo;
+    return o;
+}
+
+__device__ __forceinline__ void merge_top2(Cand &b1, Cand &b2, const Cand &o1, const Cand &o2) {
+    if (better(o1, b1)) {
+        Cand s = better(o2, b1) ? o2 : b1;
+        b1 = o1;
+        b2 = s;
+    } else {
+        if (better(o1, b2)) b2 = o1;
+    }
+}
+
+__device__ __forceinline__ uint32_t phase_count(uint32_t jl, uint32_t iter, uint32_t P) {
+    return jl > iter ? (jl - iter + P - 1) / P : 0;
+}
+
+__global__ __launch_bounds__(256) void vote_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
+                                                   const uint32_t *__restrict__ lens,
+                                                   const uint8_t *__restrict__ decided, uint64_t n,
+                                                   int seed_len, int phase_lo, int phase_hi, uint32_t cap_q,
+                                                   LrmPhaseRes *__restrict__ phase_res,
+                                                   uint64_t *__restrict__ ovf_items, LrmDevCounters *counters,
+                                                   int round) {
+    __shared__ uint64_t s_bucket[4][VOTE_SLOTS];
+    __shared__ uint64_t s_minkey[4][VOTE_SLOTS];
+    __shared__ uint64_t s_seq[4][VOTE_SLOTS];
+    __shared__ uint32_t s_count[4][VOTE_SLOTS];
+    __shared__ uint32_t s_incl[4][64];
+    __shared__ uint64_t s_k[4][64];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int P = seed_len + 1;
+    const int np = phase_hi - phase_lo + 1;
+    uint64_t item = (uint64_t) blockIdx.x * 4 + wave;
+    if (item >= n * (uint64_t) np) return;
+    uint64_t read = item / (uint64_t) np;
+    int iter = phase_lo + (int) (item % (uint64_t) np);
+    if (decided && decided[read]) return;
+
+    uint64_t *tb = s_bucket[wave];
+    uint64_t *tk = s_minkey[wave];
+    uint64_t *ts = s_seq[wave];
+    uint32_t *tc = s_count[wave];
+#pragma unroll
+    for (int t = 0; t < VOTE_SLOTS / 64; ++t) {
+        int s = lane + 64 * t;
+        tb[s] = EMPTY64; tk[s] = EMPTY64; ts[s] = EMPTY64; tc[s] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    uint32_t len = lens[read];
+    uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;
+    uint32_t cnt = phase_count(jl, (uint32_t) iter, (uint32_t) P);
+    const uint64_t *r = rec + (read * (uint64_t) P + (uint64_t) iter) * cap_q;
+    bool overflow = false;
+
+    for (uint32_t q0 = 0; q0 < cnt; q0 += 64) {
+        uint32_t q = q0 + lane;
+        uint64_t e = q < cnt ? r[q] : 0ull;
+        uint32_t rr = (uint32_t) (e >> 40);
+        uint64_t k = e & ((1ull << 40) - 1ull);
+        // inclusive scan of rr over the wavefront
+        uint32_t incl = rr;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        uint32_t total = __shfl(incl, 63);
+        if (total == 0) continue;
+        s_incl[wave][lane] = incl;
+        s_k[wave][lane] = k;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t h = lane; h < total; h += 64) {
+            // owner = first lane whose inclusive sum exceeds h
+            int lo = 0, hi = 63;
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (s_incl[wave][mid] > h) hi = mid; else lo = mid + 1;
+            }
+            uint32_t owner = (uint32_t) lo;
+            uint32_t excl = owner ? s_incl[wave][owner - 1] : 0;
+            uint32_t t = h - excl;
+            uint64_t kk = s_k[wave][owner];
+            uint64_t jq = (uint64_t) iter + (uint64_t) (q0 + owner) * (uint64_t) P;
+            uint64_t key = ix.sa[kk + t] - jq;                     // alnmain.c:363-365 (u64 wrap kept)
+            uint64_t bucket = key >> 4;                            // histo.c:26-28
+            uint64_t seq = ((uint64_t) (q0 + owner) << 32) | t;
+            uint32_t slot = (uint32_t) ((bucket * 0x9E3779B97F4A7C15ull) >> 56) & (VOTE_SLOTS - 1);
+            bool done = false;
+            for (int probe = 0; probe < VOTE_MAX_PROBE; ++probe) {
+                unsigned long long prev = atomicCAS((unsigned long long *) &tb[slot], EMPTY64, bucket);
+                if (prev == EMPTY64 || prev == bucket) {
+                    atomicAdd(&tc[slot], 1u);
+                    atomicMin((unsigned long long *) &tk[slot], key);
+                    atomicMin((unsigned long long *) &ts[slot], seq);
+                    done = true;
+                    break;
+                }
+                slot = (slot + 1) & (VOTE_SLOTS - 1);
+            }
+            if (!done) overflow = true;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (__any(overflow)) {
+        if (lane == 0) {
+            unsigned long long pos = atomicAdd(&counters->overflow_n[round], 1ull);
+            ovf_items[pos] = read * (uint64_t) P + (uint64_t) iter;
+        }
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    Cand b1 = {0u, 0u, EMPTY64}, b2 = {0u, 0u, EMPTY64};
+#pragma unroll
+    for (int t = 0; t < VOTE_SLOTS / 64; ++t) {
+        int s = lane + 64 * t;
+        Cand c = {tc[s], (uint32_t) s, ts[s]};
+        if (better(c, b1)) { b2 = b1; b1 = c; }
+        else if (better(c, b2)) b2 = c;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        Cand o1 = shfl_xor_cand(b1, m), o2 = shfl_xor_cand(b2, m);
+        merge_top2(b1, b2, o1, o2);
+    }
+    if (lane == 0) {
+        LrmPhaseRes res = {0, 0, 0, 0, 0, 0};
+        if (b1.val) { res.key1 = tk[b1.slot]; res.val1 = b1.val; res.bucket1 = tb[b1.slot]; }
+        if (b2.val) { res.key2 = tk[b2.slot]; res.val2 = b2.val; res.bucket2 = tb[b2.slot]; }
+        phase_res[read * (uint64_t) P + (uint64_t) iter] = res;
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// vote_fallback: phases whose distinct buckets do not fit the LDS table.  One 256-thread
+// workgroup per item, vote table in global memory sized from the item's own hit count.
+// Rare path (repeat-dense loci); correctness first.
+// ----------------------------------------------------------------------------------------
+struct GEntry { unsigned long long bucket, minkey, seq; unsigned int count, pad; };
+
+__global__ __launch_bounds__(256) void vote_fallback_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
+                                                            const uint32_t *__restrict__ lens, int seed_len,
+                                                            uint32_t cap_q, LrmPhaseRes *__restrict__ phase_res,
+                                                            const uint64_t *__restrict__ ovf_items,
+                                                            LrmDevCounters *counters, GEntry *tables,
+                                                            uint64_t table_cap, int round) {
+    __shared__ unsigned long long s_item;
+    __shared__ unsigned long long s_hits;
+    __shared__ Cand s_c1[256], s_c2[256];
+    const int P = seed_len + 1;
+    GEntry *tab = tables + (uint64_t) blockIdx.x * table_cap;
+    const unsigned long long n_items = counters->overflow_n[round];
+
+    while (true) {
+        if (threadIdx.x == 0) {
+            s_item = atomicAdd(&counters->overflow_done[round], 1ull);
+            s_hits = 0;
+        }
+        __syncthreads();
+        unsigned long long it = s_item;
+        if (it >= n_items) return;
+        uint64_t id = ovf_items[it];
+        uint64_t read = id / (uint64_t) P;
+        uint32_t iter = (uint32_t) (id % (uint64_t) P);
+        uint32_t len = lens[read];
+        uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;
+        uint32_t cnt = phase_count(jl, iter, (uint32_t) P);
+        const uint64_t *r = rec + (read * (uint64_t) P + iter) * cap_q;
+
+        unsigned long long my = 0;
+        for (uint32_t q = threadIdx.x; q < cnt; q += 256) my += r[q] >> 40;
+        atomicAdd(&s_hits, my);
+        __syncthreads();
+        uint64_t hits = s_hits;
+        uint64_t cap = 1024;
+        while (cap < 2 * hits) cap <<= 1;
+        if (cap > table_cap) {
+            if (threadIdx.x == 0) {
+                atomicOr(&counters->error_flags, 1ull);
+                LrmPhaseRes z = {0, 0, 0, 0, 0, 0};
+                phase_res[id] = z;
+            }
+            __syncthreads();
+            continue;
+        }
+        for (uint64_t s = threadIdx.x; s < cap; s += 256) {
+            tab[s].bucket = EMPTY64; tab[s].minkey = EMPTY64; tab[s].seq = EMPTY64; tab[s].count = 0;
+        }
+        __threadfence();
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < cnt; q += 256) {
+            uint64_t e = r[q];
+            uint32_t rr = (uint32_t) (e >> 40);
+            uint64_t k = e & ((1ull << 40) - 1ull);
+            uint64_t jq = (uint64_t) iter + (uint64_t) q * (uint64_t) P;
+            for (uint32_t t = 0; t < rr; ++t) {
+                uint64_t key = ix.sa[k + t] - jq;
+                uint64_t bucket = key >> 4;
+                uint64_t seq = ((uint64_t) q << 32) | t;
+                uint64_t slot = ((bucket * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+                while (true) {          // cap >= 2*hits: an empty slot always exists
+                    unsigned long long prev = atomicCAS(&tab[slot].bucket, EMPTY64, bucket);
+                    if (prev == EMPTY64 || prev == bucket) {
+                        atomicAdd(&tab[slot].count, 1u);
+                        atomicMin(&tab[slot].minkey, key);
+                        atomicMin(&tab[slot].seq, seq);
+                        break;
+                    }
+                    slot = (slot + 1) & (cap - 1);
+                }
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        Cand b1 = {0u, 0u, EMPTY64}, b2 = {0u, 0u, EMPTY64};
+        for (uint64_t s = threadIdx.x; s < cap; s += 256) {
+            unsigned int c = __hip_atomic_load(&tab[s].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!c) continue;
+            unsigned long long sq = __hip_atomic_load(&tab[s].seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            Cand cd = {c, (uint32_t) s, sq};
+            if (better(cd, b1)) { b2 = b1; b1 = cd; }
+            else if (better(cd, b2)) b2 = cd;
+        }
+        s_c1[threadIdx.x] = b1;
+        s_c2[threadIdx.x] = b2;
+        __syncthreads();
+        for (int stride = 128; stride > 0; stride >>= 1) {
+            if ((int) threadIdx.x < stride) {
+                Cand a1 = s_c1[threadIdx.x], a2 = s_c2[threadIdx.x];
+                merge_top2(a1, a2, s_c1[threadIdx.x + stride], s_c2[threadIdx.x + stride]);
+                s_c1[threadIdx.x] = a1;
+                s_c2[threadIdx.x] = a2;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            Cand t1 = s_c1[0], t2 = s_c2[0];
+            LrmPhaseRes res = {0, 0, 0, 0, 0, 0};
+            if (t1.val) {
+                res.key1 = __hip_atomic_load(&tab[t1.slot].minkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                res.val1 = t1.val;
+                res.bucket1 = __hip_atomic_load(&tab[t1.slot].bucket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (t2.val) {
+                res.key2 = __hip_atomic_load(&tab[t2.slot].minkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                res.val2 = t2.val;
+                res.bucket2 = __hip_atomic_load(&tab[t2.slot].bucket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            phase_res[id] = res;
+        }
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// decide: replay of alnmain.c:371-403 over the per-phase vote results.
+//   mode 0 : phase 0 only -- mark reads whose phase-0 vote passes (they are final)
+//   mode 1 : all phases, for reads not marked in mode 0
+// (double)v/num_seeds > 0.6  <=>  5v > 3*num_seeds for every feasible size.
+// ----------------------------------------------------------------------------------------
+#define MAX_PHASES 40
+__global__ __launch_bounds__(256) void decide_kernel(const LrmPhaseRes *__restrict__ phase_res,
+                                                     const uint32_t *__restrict__ lens, uint64_t n,
+                                                     int seed_len, int mode, uint8_t *__restrict__ decided,
+                                                     lrm_entry *__restrict__ best, LrmDevCounters *counters) {
+    uint64_t read = (uint64_t) blockIdx.x * 256 + threadIdx.x;
+    if (read >= n) return;
+    const int P = seed_len + 1;
+    const uint64_t num_seeds = lens[read] / (uint32_t) P;          // alnmain.c:371
+    const LrmPhaseRes *pr = phase_res + read * (uint64_t) P;
+    if (mode == 0) {
+        uint8_t d = 0;
+        if (num_seeds > 0 && P > 1) {       // a break on the LAST phase is undone (alnmain.c:400): P==1 never final here
+            LrmPhaseRes r0 = pr[0];
+            uint64_t v = r0.val1 + r0.val2;
+            if (5 * v > 3 * num_seeds) {
+                d = 1;
+                lrm_entry e = {r0.key1, r0.val1, r0.bucket1};
+                best[read] = e;
+                atomicAdd(&counters->decided_phase0, 1ull);
+            }
+        }
+        decided[read] = d;
+        return;
+    }
+    if (decided[read]) return;
+    // ot_iter_histo (alnmain.c:340,386-388,400-403): at most P entries
+    uint64_t ot_key[MAX_PHASES], ot_val[MAX_PHASES], ot_bucket[MAX_PHASES];
+    int ot_n = 0;
+    lrm_entry out = {0, 0, 0};
+    int iter;
+    for (iter = 0; iter < P; ++iter) {
+        if (num_seeds > 0) {
+            LrmPhaseRes r = pr[iter];
+            uint64_t v = r.val1 + r.val2;
+            if (5 * v > 3 * num_seeds) {
+                out.key = r.key1; out.val = r.val1; out.bucket = r.bucket1;
+                break;
+            } else if (r.val1 != 0) {
+                uint64_t key = r.key1, bucket = key >> 4;
+                bool found = false;
+                for (int t = 0; t < ot_n; ++t) {
+                    if (ot_bucket[t] == bucket) {
+                        found = true;
+                        ot_val[t] += 1;
+                        if (key < ot_key[t]) ot_key[t] = key;
+                    }
+                }
+                if (!found) { ot_key[ot_n] = key; ot_val[ot_n] = 1; ot_bucket[ot_n] = bucket; ot_n++; }
+            }
+        }
+    }
+    if (iter >= P - 1) {       // ran out, or broke on the last phase: winner comes from ot_iter_histo
+        lrm_entry t1 = {0, 0, 0};
+        for (int t = 0; t < ot_n; ++t)
+            if (t1.val < ot_val[t]) { t1.key = ot_key[t]; t1.val = ot_val[t]; t1.bucket = ot_bucket[t]; }
+        out = t1;
+    }
+    best[read] = out;
+}
+
+// ----------------------------------------------------------------------------------------
+// host launchers
+// ----------------------------------------------------------------------------------------
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    lrm_set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
+
+int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint64_t stride,
+                    const uint32_t *d_lens, uint64_t n, uint32_t max_len, uint32_t seed_len,
+                    uint32_t thres, lrm_entry *d_best, void *stream_) {
+    hipStream_t stream = (hipStream_t) stream_;
+    if (n == 0) return 0;
+    const int P = (int) seed_len + 1;
+    const uint32_t cap_q = ws->cap_q;
+    const uint64_t wpr = ws->words_per_read;
+    (void) max_len; (void) thres;
+
+    HIPCHK(hipMemsetAsync(ws->d_counters, 0, sizeof(LrmDevCounters), stream));
+    {
+        uint64_t bpr = wpr * 8;
+        uint32_t cpr = (uint32_t) ((bpr + 255) / 256);
+        uint64_t blocks = n * cpr;
+        if (blocks > 0x7fffffffull) { lrm_set_error("pack2bit grid too large"); return -1; }
+        hipLaunchKernelGGL(pack2bit_kernel, dim3((uint32_t) blocks), dim3(256), 0, stream, d_reads, stride,
+                           d_lens, (uint8_t *) ws->d_reads2, bpr, cpr, n);
+    }
+    for (int round = 0; round < 2; ++round) {
+        int lo = round == 0 ? 0 : 1;
+        int hi = round == 0 ? 0 : P - 1;
+        if (lo > hi) break;
+        int np = hi - lo + 1;
+        const uint8_t *dec = round == 0 ? nullptr : ws->d_decided;
+        uint32_t bpr = (uint32_t) (((uint64_t) np * cap_q + 255) / 256);
+        uint64_t blocks = n * bpr;
+        if (blocks > 0x7fffffffull) { lrm_set_error("seed_search grid too large: split the batch"); return -1; }
+        hipLaunchKernelGGL(seed_search_kernel, dim3((uint32_t) blocks), dim3(256), 0, stream, idx->view,
+                           ws->d_reads2, wpr, d_lens, dec, n, (int) seed_len, thres, lo, hi, cap_q, bpr,
+                           ws->d_rec);
+        uint64_t *ovf = ws->d_ovf_items + (round == 0 ? 0 : ws->n_max);
+        uint64_t items = n * (uint64_t) np;
+        uint64_t vblocks = (items + 3) / 4;
+        if (vblocks > 0x7fffffffull) { lrm_set_error("vote grid too large: split the batch"); return -1; }
+        hipLaunchKernelGGL(vote_kernel, dim3((uint32_t) vblocks), dim3(256), 0, stream, idx->view, ws->d_rec,
+                           d_lens, dec, n, (int) seed_len, lo, hi, cap_q, ws->d_phase, ovf, ws->d_counters,
+                           round);
+        hipLaunchKernelGGL(vote_fallback_kernel, dim3((uint32_t) ws->ovf_slots), dim3(256), 0, stream,
+                           idx->view, ws->d_rec, d_lens, (int) seed_len, cap_q, ws->d_phase, ovf,
+                           ws->d_counters, (GEntry *) ws->d_ovf_tables, ws->ovf_cap, round);
+        hipLaunchKernelGGL(decide_kernel, dim3((uint32_t) ((n + 255) / 256)), dim3(256), 0, stream, ws->d_phase,
+                           d_lens, n, (int) seed_len, round, ws->d_decided, d_best, ws->d_counters);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int lrm_launch_debug_seed(lrm_index *idx, const char *d_read, uint32_t len, uint32_t seed_len,
+                          uint64_t *d_reads2, uint64_t words, int32_t *d_j, uint64_t *d_rr,
+                          uint64_t *d_k, uint64_t *d_l, uint64_t cap, void *stream_) {
+    hipStream_t stream = (hipStream_t) stream_;
+    const uint32_t P = seed_len + 1;
+    uint32_t jl = len > seed_len ? len - seed_len : 0;
+    uint32_t cap_q = (jl + P - 1) / P;
+    if (cap_q == 0) cap_q = 1;
+    if ((uint64_t) cap_q * P > cap) { lrm_set_error("debug seed buffer too small"); return -1; }
+    uint64_t bpr = words * 8;
+    uint32_t cpr = (uint32_t) ((bpr + 255) / 256);
+    uint32_t *d_len1 = (uint32_t *) (d_reads2 + words);     // caller reserves one extra word for the length
+    HIPCHK(hipMemcpyAsync(d_len1, &len, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(pack2bit_kernel, dim3(cpr), dim3(256), 0, stream, d_read, (uint64_t) 0, d_len1,
+                       (uint8_t *) d_reads2, bpr, cpr, (uint64_t) 1);
+    uint32_t items = cap_q * P;
+    hipLaunchKernelGGL(seed_search_debug_kernel, dim3((items + 255) / 256), dim3(256), 0, stream, idx->view,
+                       d_reads2, len, (int) seed_len, cap_q, d_j, d_rr, d_k, d_l);
+    HIPCHK(hipGetLastError());
+    return (int) cap_q;
+}

@@ -1,0 +1,166 @@
+"""Host-side index objects (CPU construction, files) and their device upload.
+
+Mirrors the reference's index life cycle: `accidx` (asindex.c) builds the five files,
+`init()` (alnmain.c:179-256) loads them; here `HostIndex.build()/read()` produce the same
+in-memory structs and `DeviceIndex` holds their MI355X image."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import check, lib
+
+
+def _np_view(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    addr = ptr if isinstance(ptr, int) else C.cast(ptr, C.c_void_p).value
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(addr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+class HostIndex:
+    """dna_fmi + lc_hash + sa_mem + content + mta, in the reference's in-memory layouts."""
+
+    def __init__(self):
+        self.h = capi.HostIndex()
+        self._owned = False
+
+    @classmethod
+    def build(cls, seqs, names=None, o_ratio=32, hlen=12, n_seed=7):
+        """seqs: list of byte strings / uint8 arrays (forward strands)."""
+        self = cls()
+        bufs = [bytes(memoryview(np.ascontiguousarray(s))) if isinstance(s, np.ndarray) else bytes(s) for s in seqs]
+        n = len(bufs)
+        seqp = (C.c_char_p * n)(*bufs)
+        namep = (C.c_char_p * n)(*[(nm.encode() if isinstance(nm, str) else nm) for nm in names]) if names else None
+        lens = (C.c_uint64 * n)(*[len(b) for b in bufs])
+        cat = C.c_void_p()
+        cat_len = C.c_uint64()
+        mta = C.POINTER(capi.MtaEntry)()
+        check(lib.lrm_cat_from_seqs(namep, seqp, lens, n, n_seed, C.byref(cat), C.byref(cat_len), C.byref(mta)),
+              "lrm_cat_from_seqs")
+        try:
+            check(lib.lrm_host_index_build(cat, cat_len.value, mta, n, o_ratio, hlen, C.byref(self.h)),
+                  "lrm_host_index_build")
+        finally:
+            C.CDLL(None).free(cat)
+            lib.lrm_mta_free(mta, n)
+        self._owned = True
+        return self
+
+    @classmethod
+    def read(cls, genome):
+        self = cls()
+        check(lib.lrm_host_index_read(genome.encode(), C.byref(self.h)), "lrm_host_index_read")
+        self._owned = True
+        return self
+
+    def write(self, genome):
+        check(lib.lrm_host_index_write(C.byref(self.h), genome.encode()), "lrm_host_index_write")
+
+    def close(self):
+        if self._owned:
+            lib.lrm_host_index_free(C.byref(self.h))
+            self._owned = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # numpy views (no copies)
+    @property
+    def length(self):
+        return int(self.h.fmi.length)
+
+    @property
+    def hlen(self):
+        return int(self.h.lch.hlen)
+
+    @property
+    def mta_len(self):
+        return int(self.h.mta_len)
+
+    def c(self):
+        return _np_view(self.h.fmi.c, 256, np.uint64)
+
+    def o(self):
+        return _np_view(self.h.fmi.o, int(self.h.fmi.o_len), np.uint64)
+
+    def csa(self):
+        return _np_view(self.h.fmi.csa, int(self.h.fmi.csa_len), np.uint64)
+
+    def bwt(self):
+        return _np_view(self.h.fmi.bwt, self.length, np.uint8)
+
+    def lc(self):
+        return _np_view(self.h.lch.lc, int(self.h.lch.len), np.uint64)
+
+    def sa_raw(self):
+        return _np_view(self.h.sa.mem, int(self.h.sa.len), np.uint64)
+
+    def sa(self):
+        return self.sa_raw() & np.uint64((1 << 40) - 1)
+
+    def content(self):
+        return _np_view(self.h.content, int(self.h.con_len), np.uint8)
+
+    def mta(self):
+        return [(self.h.mta[i].name.decode() if self.h.mta[i].name else "", int(self.h.mta[i].offset),
+                 int(self.h.mta[i].seq_len)) for i in range(self.mta_len)]
+
+    def blob_bytes(self):
+        return int(lib.lrm_index_blob_bytes(self.length, self.hlen, self.mta_len))
+
+    def pack_blob(self, out=None):
+        """Serialise to the device image in host memory (numpy uint8)."""
+        n = self.blob_bytes()
+        if out is None:
+            out = np.empty(n, dtype=np.uint8)
+        check(lib.lrm_index_pack_blob(C.byref(self.h.fmi), C.byref(self.h.lch), C.byref(self.h.sa), self.h.content,
+                                      self.h.con_len, self.h.mta, self.h.mta_len, out.ctypes.data, n),
+              "lrm_index_pack_blob")
+        return out
+
+
+class DeviceIndex:
+    """Device-resident index image (lrm_index*)."""
+
+    def __init__(self, handle, keep=None):
+        self.handle = handle
+        self._keep = keep      # e.g. the torch tensor that owns an adopted blob
+
+    @classmethod
+    def upload(cls, host: HostIndex, device=0):
+        hnd = C.c_void_p()
+        check(lib.lrm_index_upload(C.byref(hnd), C.byref(host.h.fmi), C.byref(host.h.lch), C.byref(host.h.sa),
+                                   host.h.content, host.h.con_len, host.h.mta, host.h.mta_len, device),
+              "lrm_index_upload")
+        return cls(hnd)
+
+    @classmethod
+    def upload_blob(cls, blob: np.ndarray, device=0):
+        hnd = C.c_void_p()
+        check(lib.lrm_index_upload_blob(C.byref(hnd), blob.ctypes.data, blob.nbytes, device), "lrm_index_upload_blob")
+        return cls(hnd)
+
+    @classmethod
+    def adopt(cls, blob_tensor, device=0):
+        """blob_tensor: torch uint8 CUDA tensor holding the image (e.g. after an RCCL broadcast)."""
+        hnd = C.c_void_p()
+        check(lib.lrm_index_adopt_device(C.byref(hnd), blob_tensor.data_ptr(), blob_tensor.numel(), device),
+              "lrm_index_adopt_device")
+        return cls(hnd, keep=blob_tensor)
+
+    def close(self):
+        if self.handle:
+            lib.lrm_index_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

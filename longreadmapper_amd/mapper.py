@@ -1,0 +1,140 @@
+"""Batch entry points of the hot path, host-buffer and device-buffer flavours.
+
+`seed_batch` / `extend_batch` are PART 1 / PART 2 of single_end() (alnmain.c:333-451) for a
+whole batch; names, argument meaning and data conventions follow the reference (best[],
+cig[], limit[], meta_r[], m[])."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import check, lib
+
+ENTRY_DT = np.dtype([("key", "<u8"), ("val", "<u8"), ("bucket", "<u8")])
+META_DT = np.dtype([("loc", "<u8"), ("off", "<u8"), ("seq_id", "<i4"), ("strand", "u1"), ("_pad", "V3")])
+assert ENTRY_DT.itemsize == 24 and META_DT.itemsize == 24
+
+DEFAULT_SEED_LEN = 20      # alnmain.c:577-580
+DEFAULT_THRES = 300
+DEFAULT_GACT = (320, 120, 128)
+
+
+def seed_batch(index, reads, lens, seed_len=DEFAULT_SEED_LEN, thres=DEFAULT_THRES):
+    """Host buffers in, best[] out (numpy structured array key/val/bucket)."""
+    reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    n, stride = reads.shape
+    best = np.zeros(n, dtype=ENTRY_DT)
+    p = capi.Params(n, seed_len, thres)
+    check(lib.lrm_seed_batch(index.handle, reads.ctypes.data, stride, lens.ctypes.data, n, p, best.ctypes.data),
+          "lrm_seed_batch")
+    return best
+
+
+def extend_batch(index, reads, lens, best, gact=DEFAULT_GACT):
+    """Host buffers; `reads` is modified in place (reverse-strand reads are rev-comped).
+
+    Returns dict(ops=(n, store_stride) uint8, n_ops, score, meta, meta_r)."""
+    assert reads.dtype == np.uint8 and reads.flags.c_contiguous and reads.flags.writeable
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    best = np.ascontiguousarray(best, dtype=ENTRY_DT)
+    n, stride = reads.shape
+    max_len = int(lens.max()) if n else 0
+    store_stride = max(2 * max_len, 1)                    # alnmain.c:316-320
+    store = np.zeros((n, store_stride), dtype=np.uint8)
+    cig = (capi.Cigar * max(n, 1))()
+    score = np.zeros(n, dtype=np.int32)
+    meta = np.zeros(n, dtype=META_DT)
+    meta_r = np.zeros(n, dtype=np.int32)
+    gp = capi.GactParams(*gact)
+    check(lib.lrm_extend_batch(index.handle, reads.ctypes.data, stride, lens.ctypes.data, n, best.ctypes.data, gp,
+                               C.cast(cig, C.c_void_p), store.ctypes.data, store_stride, score.ctypes.data,
+                               meta.ctypes.data, meta_r.ctypes.data), "lrm_extend_batch")
+    n_ops = np.array([cig[i].n_cigar_op for i in range(n)], dtype=np.int32)
+    return dict(ops=store, n_ops=n_ops, score=score, meta=meta, meta_r=meta_r)
+
+
+def result_flags(score, meta_r, meta):
+    n = len(score)
+    flag = np.zeros(n, dtype=np.int32)
+    mapq = np.zeros(n, dtype=np.int32)
+    valid = np.zeros(n, dtype=np.int32)
+    score = np.ascontiguousarray(score, dtype=np.int32)
+    meta_r = np.ascontiguousarray(meta_r, dtype=np.int32)
+    meta = np.ascontiguousarray(meta, dtype=META_DT)
+    lib.lrm_result_flags(score.ctypes.data, meta_r.ctypes.data, meta.ctypes.data, n, flag.ctypes.data,
+                         mapq.ctypes.data, valid.ctypes.data)
+    return flag, mapq, valid
+
+
+class DeviceMapper:
+    """Device-resident batches: torch tensors own the HBM buffers, kernels run on torch's
+    current stream (so torch.cuda.Event brackets them)."""
+
+    def __init__(self, index, n_max, max_len, seed_len=DEFAULT_SEED_LEN, thres=DEFAULT_THRES, gact=DEFAULT_GACT,
+                 device=0):
+        import torch
+        self.torch = torch
+        self.index = index
+        self.n_max, self.max_len = n_max, max_len
+        self.seed_len, self.thres, self.gact = seed_len, thres, gact
+        self.dev = torch.device("cuda", device)
+        ws = C.c_void_p()
+        check(lib.lrm_workspace_create(C.byref(ws), index.handle, n_max, max_len, seed_len, thres),
+              "lrm_workspace_create")
+        self.ws = ws
+        self.store_stride = 2 * max_len
+        self.best = torch.zeros((n_max, 3), dtype=torch.int64, device=self.dev)       # lrm_entry
+        self.store = torch.zeros((n_max, self.store_stride), dtype=torch.uint8, device=self.dev)
+        self.n_ops = torch.zeros(n_max, dtype=torch.int32, device=self.dev)
+        self.score = torch.zeros(n_max, dtype=torch.int32, device=self.dev)
+        self.meta = torch.zeros((n_max, 24), dtype=torch.uint8, device=self.dev)      # lrm_seq_meta
+        self.meta_r = torch.zeros(n_max, dtype=torch.int32, device=self.dev)
+
+    def workspace_bytes(self):
+        return int(lib.lrm_workspace_bytes(self.ws))
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def seed(self, d_reads, d_lens, n=None):
+        n = d_reads.shape[0] if n is None else n
+        p = capi.Params(n, self.seed_len, self.thres)
+        check(lib.lrm_seed_batch_dev(self.index.handle, self.ws, d_reads.data_ptr(), d_reads.stride(0),
+                                     d_lens.data_ptr(), n, self.max_len, p, self.best.data_ptr(), self._stream()),
+              "lrm_seed_batch_dev")
+
+    def extend(self, d_reads, d_lens, n=None):
+        n = d_reads.shape[0] if n is None else n
+        gp = capi.GactParams(*self.gact)
+        check(lib.lrm_extend_batch_dev(self.index.handle, self.ws, d_reads.data_ptr(), d_reads.stride(0),
+                                       d_lens.data_ptr(), n, self.max_len, self.best.data_ptr(), gp,
+                                       self.store.data_ptr(), self.store_stride, self.n_ops.data_ptr(),
+                                       self.score.data_ptr(), self.meta.data_ptr(), self.meta_r.data_ptr(),
+                                       self._stream()), "lrm_extend_batch_dev")
+
+    def stats(self):
+        st = capi.Stats()
+        check(lib.lrm_workspace_stats(self.ws, C.byref(st), self._stream()), "lrm_workspace_stats")
+        return dict(vote_overflow_items=int(st.vote_overflow_items),
+                    reads_decided_phase0=int(st.reads_decided_phase0), gact_tiles=int(st.gact_tiles))
+
+    def results(self, n):
+        """Copy the outputs of the last seed+extend to numpy (host)."""
+        best = self.best[:n].cpu().numpy().view(np.uint64).reshape(n, 3)
+        out = np.zeros(n, dtype=ENTRY_DT)
+        out["key"], out["val"], out["bucket"] = best[:, 0], best[:, 1], best[:, 2]
+        meta = self.meta[:n].cpu().numpy().reshape(-1).view(META_DT)
+        return dict(best=out, ops=self.store[:n].cpu().numpy(), n_ops=self.n_ops[:n].cpu().numpy(),
+                    score=self.score[:n].cpu().numpy(), meta=meta, meta_r=self.meta_r[:n].cpu().numpy())
+
+    def close(self):
+        if self.ws:
+            lib.lrm_workspace_free(self.ws)
+            self.ws = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

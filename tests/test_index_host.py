@@ -1,0 +1,139 @@
+"""Product CPU index builder (SA-IS + SA-scan lchash) vs the oracle's restatement of
+fmi_build / lc_build (comparison sort + 4^hlen backward searches), the on-disk formats
+(Notes.txt:6-29, fmidx.c:221-275, lchash.c:106-127, sa_use.h:31-46, alnmain.c:125-140) and the
+reference's own ui40 helpers where oracle/_ref is available."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import orc
+from longreadmapper_amd import capi, index, synth
+
+
+def _cases():
+    rng = np.random.default_rng(3)
+    yield "random-1k", [synth.reference(1000, seed=2)]
+    yield "two-seqs", [synth.reference(700, seed=3), synth.reference(333, seed=4)]
+    yield "tandem", [np.frombuffer((b"ACGTTGCA" * 60 + b"GGATC" * 31), dtype=np.uint8)]
+    yield "homopolymer", [np.frombuffer(b"A" * 200 + b"C" * 50 + b"A" * 77, dtype=np.uint8)]
+    yield "planted", [synth.reference(6000, seed=5, repeat_frac=0.3, rep_len=150, rep_copies=6, rep_div=0.02)]
+    yield "tiny", [np.frombuffer(b"ACGTACGATT", dtype=np.uint8)]
+    _ = rng
+
+
+@pytest.mark.parametrize("name,seqs", list(_cases()), ids=[n for n, _ in _cases()])
+@pytest.mark.parametrize("hlen", [2, 5, 7])
+def test_builder_equals_oracle(name, seqs, hlen):
+    if sum(len(s) for s in seqs) * 2 < hlen + 2:
+        pytest.skip("too short")
+    hi = index.HostIndex.build(seqs, o_ratio=32, hlen=hlen)
+    oi = orc.OracleIndex.build(seqs, o_ratio=32, hlen=hlen)
+    assert hi.length == oi.length
+    assert bytes(hi.content()) == bytes(oi.content())
+    assert [(o, l) for _, o, l in hi.mta()] == oi.mta()
+    assert np.array_equal(hi.sa(), oi.sa())
+    assert np.array_equal(hi.c(), oi.c())
+    assert bytes(hi.bwt()) == bytes(oi.bwt())
+    assert np.array_equal(hi.o(), oi.o())
+    assert np.array_equal(hi.csa(), oi.csa())
+    assert np.array_equal(hi.lc(), oi.lc())
+
+
+def test_sa_is_sorted_and_complete_large():
+    # size-independent property at a size the comparison-sort oracle would not like
+    ref = synth.reference(300_000, seed=9, repeat_frac=0.1, rep_len=300, rep_copies=20)
+    hi = index.HostIndex.build([ref], hlen=6)
+    sa = hi.sa().astype(np.int64)
+    L = hi.length
+    assert np.array_equal(np.sort(sa), np.arange(L))
+    text = hi.content()
+    # adjacent suffixes in order: compare 64-byte prefixes (ties beyond that are checked on a sample)
+    pad = np.concatenate([text, np.zeros(64, dtype=np.uint8)])
+    win = np.lib.stride_tricks.sliding_window_view(pad, 64)
+    a, b = win[sa[:-1]], win[sa[1:]]
+    neq = a != b
+    first = neq.argmax(axis=1)
+    tie = ~neq.any(axis=1)
+    rows = np.arange(L - 1)
+    assert np.all((a[rows, first] < b[rows, first]) | tie)
+    for r in np.nonzero(tie)[0][:200]:
+        x, y = int(sa[r]), int(sa[r + 1])
+        assert bytes(text[x:]) < bytes(text[y:])
+
+
+def test_cat_layout_and_n_replacement():
+    hi = index.HostIndex.build([b"acgtn", b"GGN"], names=["chrA", "chrB"], hlen=2)
+    cat = bytes(hi.content())
+    assert len(cat) == 2 * 5 + 2 * 3 + 1 and cat.endswith(b"$")
+    assert cat[:4] == b"ACGT" and cat[4:5] in (b"A", b"C", b"G", b"T")
+    fwd = cat[:5]
+    assert cat[5:10] == orc.rev_comp(fwd)                       # fwd + revcomp per record (asindex.c:97-102)
+    assert hi.mta() == [("chrA", 0, 5), ("chrB", 10, 3)]
+
+
+def test_file_formats_roundtrip(tmp_path):
+    ref = synth.reference(5000, seed=12)
+    hi = index.HostIndex.build([ref, ref[:100]], names=["one", "two"], hlen=5)
+    g = str(tmp_path / "ref.fa")
+    hi.write(g)
+    L = hi.length
+    # sizes documented in SURVEY section 8: .sa5 = 5L, .lch = 4+8+8*2*4^h, .mfi formula
+    assert os.path.getsize(g + ".cat") == L
+    assert os.path.getsize(g + ".cat.sa5") == 5 * L                       # test/test-ui40read.cc:39-57
+    assert os.path.getsize(g + ".cat.lch") == 4 + 8 + 8 * 2 * 4 ** 5
+    o_len, csa_len = 4 * (L // 32 + 1), L // 4 + 1
+    assert os.path.getsize(g + ".cat.mfi") == 2048 + 4 + 8 + 8 * o_len + 8 + L + 4 + 8 + 8 * csa_len
+    raw = open(g + ".cat.mfi", "rb").read()
+    assert struct.unpack_from("<i", raw, 2048)[0] == 32 and struct.unpack_from("<Q", raw, 2052)[0] == o_len
+    mta = open(g + ".mta", "rb").read()
+    assert mta[:8] == struct.pack("<Q", 3) and mta[8:11] == b"one"       # mstring_write: length, bytes
+    assert struct.unpack_from("<QQ", mta, 11) == (0, 5000)
+    back = index.HostIndex.read(g)
+    assert back.length == L and back.hlen == 5
+    for f in ("c", "o", "csa", "bwt", "lc", "sa", "content"):
+        assert np.array_equal(getattr(back, f)(), getattr(hi, f)()), f
+    assert back.mta() == hi.mta()
+    # the reference's own reader (sa_use.h ui40_fread) sees the same values
+    rl = orc.ref_ui40_lib()
+    if rl is not None:
+        assert rl.ref_ui40_sizeof() == 8                                 # 8 bytes in RAM, 5 on disk
+        out = np.zeros(L, dtype=np.uint64)
+        n = rl.ref_ui40_fread_path((g + ".cat.sa5").encode(), out.ctypes.data, L)
+        assert n == L and np.array_equal(out, hi.sa())
+
+
+def test_ui40_in_memory_layout_matches_reference():
+    # test/test-ui40read.cc:12-37: struct {u32 low; u8 high} written raw is 8 bytes
+    assert C.sizeof(capi.Ui40) == 8
+    rl = orc.ref_ui40_lib()
+    if rl is None:
+        pytest.skip("oracle/_ref not built here")
+    b = (C.c_uint8 * 8)(4, 3, 2, 1, 5, 0, 0, 0)
+    assert rl.ref_ui40_from_bytes_convert(b) == (5 << 32) | 0x01020304
+
+
+def test_accidx_from_fasta(tmp_path):
+    ref = synth.reference(3000, seed=21)
+    fa = tmp_path / "g.fa"
+    with open(fa, "wb") as f:
+        f.write(b">chr1 some description\n")
+        s = bytes(ref)
+        for i in range(0, len(s), 70):
+            f.write(s[i:i + 70].lower() + b"\n")
+        f.write(b">chr2\n" + bytes(ref[:500]) + b"\n")
+    assert capi.lib.lrm_accidx(str(fa).encode(), 32, 6, 1) == 0
+    got = index.HostIndex.read(str(fa))
+    want = index.HostIndex.build([ref, ref[:500]], names=["chr1", "chr2"], hlen=6)
+    assert got.mta() == want.mta()
+    for f in ("c", "o", "csa", "bwt", "lc", "sa", "content"):
+        assert np.array_equal(getattr(got, f)(), getattr(want, f)()), f
+
+
+def test_pack_blob_rejects_inconsistent_index():
+    hi = index.HostIndex.build([synth.reference(500, seed=1)], hlen=3)
+    hi.o()[5] += 1
+    with pytest.raises(capi.LrmError, match="O table disagrees"):
+        hi.pack_blob()
