@@ -125,6 +125,14 @@ SYMBOLS = {
 
 
 def _load():
+    # torch bundles its own libamdhip64.so.7 (+ HSA runtime).  Two HIP runtimes in one process do
+    # not both get the GPU, and the dynamic linker keys on the SONAME: whichever is loaded first
+    # serves both.  torch.distributed / torch tensors are this package's device plumbing, so let
+    # torch's runtime win: import it before liblrm_accel.so pulls in /opt/rocm's.
+    try:
+        import torch  # noqa: F401
+    except Exception:      # torch absent: the system runtime is the only one
+        pass
     path = _build.ACCEL_LIB
     if not os.path.exists(path):
         path = _build.build_accel()

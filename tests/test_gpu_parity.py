@@ -1,0 +1,212 @@
+"""GPU parity: the HIP path (through the C-ABI of liblrm_accel.so) against the CPU oracle on the
+same seeded inputs.  Bit-exact: every compared quantity is an integer, byte or index."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+import workloads
+from longreadmapper_amd import capi, index, mapper, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev_indexes(gpu):
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            sc = workloads.scenario(name)
+            cache[name] = (sc, index.DeviceIndex.upload(sc["hi"], gpu), orc.OracleIndex.from_host_index(sc["hi"]))
+        return cache[name]
+    yield get
+    for _, di, _ in cache.values():
+        di.close()
+
+
+def _gpu_gact(q, d, T, O, W):
+    qa = np.frombuffer(q, dtype=np.uint8)
+    da = np.frombuffer(d, dtype=np.uint8)
+    ops = np.zeros(len(q) + len(d) + 16, dtype=np.uint8)
+    n_ops, score = C.c_int(), C.c_int()
+    capi.check(capi.lib.lrm_debug_gact(qa.ctypes.data, len(q), da.ctypes.data, len(d), capi.GactParams(T, O, W),
+                                       ops.ctypes.data, C.byref(n_ops), C.byref(score), 0), "lrm_debug_gact")
+    return score.value, bytes(ops[:n_ops.value])
+
+
+def _mutate(rng, s, sub, ins, dele):
+    out = bytearray()
+    for c in s:
+        x = rng.random()
+        if x < dele:
+            continue
+        if x < dele + sub:
+            c = rng.choice([b for b in b"ACGT" if b != c])
+        out.append(c)
+        if rng.random() < ins:
+            out.append(rng.choice(list(b"ACGT")))
+    return bytes(out)
+
+
+GACT_PARAMS = [(320, 120, 128), (128, 32, 64), (64, 16, 32), (16, 0, 2), (320, 120, 20), (512, 120, 128),
+               (100, 99, 128), (33, 7, 66), (320, 0, 128)]
+
+
+@pytest.mark.parametrize("T,O,W", GACT_PARAMS)
+def test_gact_kernel_vs_oracle(gpu, T, O, W):
+    rng = np.random.default_rng(T * 1000 + O * 10 + W)
+    ref = bytes(synth.reference(20000, seed=3))
+    sizes = [1, 2, 5, 31, 63, 64, 65, 127, 199, 200, 201, 319, 320, 321, 500, 1000, 2500]
+    for n in sizes:
+        for prof in ((0, 0, 0), (0.04, 0.03, 0.03), (0.015, 0.09, 0.045), (0.2, 0.1, 0.1)):
+            p = int(rng.integers(0, len(ref) - 3 * n - 64))
+            q = _mutate(rng, ref[p:p + n], *prof) or b"C"
+            for m in {len(q), max(1, len(q) - 7), len(q) + 13}:
+                d = ref[p:p + m]
+                want = orc.gact(q, d, T, O, W)
+                got = _gpu_gact(q, d, T, O, W)
+                assert got == (want[0], want[1]), (n, prof, m)
+    # unrelated sequences and a start offset (leading gap)
+    q, d = ref[100:700], ref[9000:9600]
+    assert _gpu_gact(q, d, T, O, W) == orc.gact(q, d, T, O, W)[:2]
+    q, d = ref[140:900], ref[100:860]
+    assert _gpu_gact(q, d, T, O, W) == orc.gact(q, d, T, O, W)[:2]
+
+
+def test_gact_rejects_unsupported_params(gpu):
+    q = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ops = np.zeros(16, dtype=np.uint8)
+    a, b = C.c_int(), C.c_int()
+    for gp in ((320, 320, 128), (320, 120, 129), (8, 0, 8), (320, 120, 256)):
+        rc = capi.lib.lrm_debug_gact(q.ctypes.data, 4, q.ctypes.data, 4, capi.GactParams(*gp), ops.ctypes.data,
+                                     C.byref(a), C.byref(b), 0)
+        assert rc < 0 and b"unsupported GACT" in capi.lib.lrm_last_error()
+
+
+@pytest.mark.parametrize("name", ["clean-1k", "ont-2k", "pacbio-3k-h12", "ragged", "seed12", "seed32",
+                                  "seed-below-hlen", "repeats-ties"])
+def test_seed_search_per_seed(dev_indexes, name):
+    """K1 alone: (j, rr, k, l) of every seed of a read, also for failed searches (k > l as the
+    reference leaves them, fmidx.c:310-312)."""
+    sc, di, oi = dev_indexes(name)
+    s = sc["seed_len"]
+    for i in range(0, len(sc["lens"]), 5):
+        ln = int(sc["lens"][i])
+        read = np.ascontiguousarray(sc["reads"][i, :max(ln, 1)])
+        cap = (ln // (s + 1) + 2) * (s + 1)
+        j = np.zeros(cap, dtype=np.int32)
+        rr = np.zeros(cap, dtype=np.uint64)
+        k = np.zeros(cap, dtype=np.uint64)
+        l = np.zeros(cap, dtype=np.uint64)
+        n_out = C.c_uint64()
+        cap_q = capi.check(capi.lib.lrm_debug_seed_search(di.handle, read.ctypes.data, ln, s, sc["thres"],
+                                                          j.ctypes.data, rr.ctypes.data, k.ctypes.data,
+                                                          l.ctypes.data, cap, C.byref(n_out)), "debug_seed_search")
+        got = {}
+        for x in range(n_out.value):
+            if j[x] >= 0:
+                got[int(j[x])] = (int(rr[x]), int(k[x]), int(l[x]))
+        # the oracle with thres=0 never votes, so it never breaks: all phases, every seed position
+        tr = oi.seed_read(bytes(sc["reads"][i, :ln]), s, 0, trace=True)
+        want = {jj: (r_, k_, l_) for jj, r_, k_, l_ in tr["seeds"]}
+        assert got == want, (name, i)
+        assert cap_q >= 1
+
+
+@pytest.mark.parametrize("name", workloads.SEED_SCENARIOS)
+def test_seed_batch_vs_oracle(dev_indexes, name):
+    sc, di, oi = dev_indexes(name)
+    want, phases = oi.seed_batch(sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+    got = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+    for f in ("key", "val", "bucket"):
+        assert np.array_equal(got[f], want[f]), (name, f, np.nonzero(got[f] != want[f])[0][:10])
+    if name == "clean-1k":
+        assert (phases == 1).mean() > 0.7          # exercised the phase-0 early decision
+    if name == "ont-2k":
+        assert (phases == 21).all()
+
+
+def test_vote_overflow_uses_global_table(dev_indexes, gpu):
+    sc, di, oi = dev_indexes("repeats-overflow")
+    import torch
+    n, stride = sc["reads"].shape
+    dm = mapper.DeviceMapper(di, n, stride - 1, sc["seed_len"], sc["thres"], device=gpu)
+    d_reads = torch.from_numpy(sc["reads"]).cuda()
+    d_lens = torch.from_numpy(sc["lens"].astype(np.int32)).cuda()
+    dm.seed(d_reads, d_lens)
+    st = dm.stats()
+    assert st["vote_overflow_items"] > 0
+    want, _ = oi.seed_batch(sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+    got = dm.results(n)["best"]
+    for f in ("key", "val", "bucket"):
+        assert np.array_equal(got[f], want[f])
+    dm.close()
+
+
+@pytest.mark.parametrize("name", ["clean-1k", "ont-2k", "pacbio-3k-h12", "ragged", "repeats-ties"])
+@pytest.mark.parametrize("gact", [(320, 120, 128), (128, 64, 32)])
+def test_extend_batch_vs_oracle(dev_indexes, name, gact):
+    sc, di, oi = dev_indexes(name)
+    best, _ = oi.seed_batch(sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+    if name == "ragged":     # also: a wrapped diagonal, a locus straddling the strand boundary, the last bases
+        best = best.copy()
+        N = len(sc["seqs"][0])
+        best["key"][5] = (1 << 64) - 3
+        best["key"][6] = N - 10
+        best["key"][7] = 2 * N - 41
+        best["key"][8] = 2 * N + 5
+    r_cpu = sc["reads"].copy()
+    want = oi.extend_batch(r_cpu, sc["lens"], best, gact)
+    r_gpu = sc["reads"].copy()
+    got = mapper.extend_batch(di, r_gpu, sc["lens"], best, gact)
+    assert np.array_equal(got["meta_r"], want["meta_r"])
+    for f in ("loc", "off", "seq_id", "strand"):
+        assert np.array_equal(got["meta"][f], want["meta"][f]), f
+    assert np.array_equal(got["score"], want["score"])
+    assert np.array_equal(got["n_ops"], want["n_ops"])
+    for i in range(len(best)):
+        k = int(want["n_ops"][i])
+        assert bytes(got["ops"][i, :k]) == bytes(want["ops"][i, :k]), (name, i)
+    assert np.array_equal(r_gpu, r_cpu)            # reverse-strand reads were rev-comped in place
+    assert (want["meta"]["strand"] == 1).any() or name == "ragged"
+    flag, mapq, valid = mapper.result_flags(got["score"], got["meta_r"], got["meta"])
+    assert ((flag & 4) != 0).sum() == ((want["meta_r"] == 0) | (want["score"] == -1)).sum()
+
+
+def test_device_resident_pipeline_equals_host_path(dev_indexes, gpu):
+    import torch
+    sc, di, oi = dev_indexes("ont-2k")
+    n, stride = sc["reads"].shape
+    dm = mapper.DeviceMapper(di, n, stride - 1, sc["seed_len"], sc["thres"], device=gpu)
+    d_reads = torch.from_numpy(sc["reads"].copy()).cuda()
+    d_lens = torch.from_numpy(sc["lens"].astype(np.int32)).cuda()
+    for _ in range(2):                              # reads are rev-comped in place: reload per pass
+        d_reads.copy_(torch.from_numpy(sc["reads"]))
+        dm.seed(d_reads, d_lens)
+        dm.extend(d_reads, d_lens)
+    torch.cuda.synchronize()
+    res = dm.results(n)
+    best = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+    assert np.array_equal(res["best"], best)
+    r = sc["reads"].copy()
+    ext = mapper.extend_batch(di, r, sc["lens"], best)
+    assert np.array_equal(res["score"], ext["score"]) and np.array_equal(res["n_ops"], ext["n_ops"])
+    assert np.array_equal(d_reads.cpu().numpy(), r)
+    st = dm.stats()
+    assert st["gact_tiles"] > 0 and st["vote_overflow_items"] == 0
+    dm.close()
+
+
+def test_blob_roundtrip_and_adopt(dev_indexes, gpu):
+    """The image broadcast path: pack on the host, move as bytes, adopt on the device."""
+    import torch
+    sc, di, oi = dev_indexes("clean-1k")
+    blob = sc["hi"].pack_blob()
+    t = torch.from_numpy(blob).cuda()
+    d2 = index.DeviceIndex.adopt(t, gpu)
+    a = mapper.seed_batch(di, sc["reads"], sc["lens"])
+    b = mapper.seed_batch(d2, sc["reads"], sc["lens"])
+    assert np.array_equal(a, b)
+    d2.close()
