@@ -164,14 +164,24 @@ int lrm_extend_batch_dev(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint6
                          lrm_seq_meta *d_meta, int32_t *d_meta_r, void *stream);
 
 /* Counters of the last *_dev call on this workspace (device->host copy, syncs
- * the stream): reads that needed the global-memory vote table, seed phases
- * evaluated, GACT tiles.  For tests / bench bookkeeping only. */
+ * the stream): vote items per table tier, reads decided in
+ * phase 0, GACT tiles.  For tests / bench bookkeeping only. */
 typedef struct lrm_stats {
-    uint64_t vote_overflow_items;   /* (read,phase) items re-run with the global table */
+    uint64_t vote_tier2_items;      /* (read,phase) items voted with the 2048-slot workgroup table */
+    uint64_t vote_tier3_items;      /* ... with the multi-pass workgroup table */
     uint64_t reads_decided_phase0;  /* reads whose vote passed 0.6 in phase 0 */
     uint64_t gact_tiles;
 } lrm_stats;
 int lrm_workspace_stats(lrm_workspace *ws, lrm_stats *out, void *stream);
+
+/* Per-kernel timing with HIP events recorded on the launch stream (bench bookkeeping).
+ * Kernel order: pack2bit, seed_search, vote, vote_fallback, decide, locus_resolve, revcomp, gact.
+ * lrm_workspace_timing synchronises the stream, ADDS the elapsed milliseconds and launch counts
+ * of everything recorded since the last call into ms[8] / launches[8], and resets the record. */
+#define LRM_N_KERNELS 8
+int lrm_workspace_set_timing(lrm_workspace *ws, int enable);
+int lrm_workspace_timing(lrm_workspace *ws, double *ms, uint64_t *launches, void *stream);
+const char *lrm_kernel_name(int kernel);
 
 /* Debug/parity taps (tests only): per-seed search results of one read as the
  * seed kernel produced them, in (phase, ordinal) order: j, rr, k, l. */

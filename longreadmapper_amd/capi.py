@@ -59,8 +59,8 @@ class GactParams(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("vote_overflow_items", C.c_uint64), ("reads_decided_phase0", C.c_uint64),
-                ("gact_tiles", C.c_uint64)]
+    _fields_ = [("vote_tier2_items", C.c_uint64), ("vote_tier3_items", C.c_uint64),
+                ("reads_decided_phase0", C.c_uint64), ("gact_tiles", C.c_uint64)]
 
 
 class HostIndex(C.Structure):          # lrm_index_host.h
@@ -98,6 +98,9 @@ SYMBOLS = {
                                        C.c_uint32, C.c_void_p, GactParams, C.c_void_p, C.c_uint64, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lrm_workspace_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats), C.c_void_p]),
+    "lrm_workspace_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "lrm_workspace_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lrm_kernel_name": (C.c_char_p, [C.c_int]),
     "lrm_debug_seed_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, u64p]),
     "lrm_debug_gact": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, GactParams, C.c_void_p,

@@ -93,17 +93,18 @@ __global__ __launch_bounds__(256) void revcomp_kernel(char *__restrict__ reads, 
 // GACT
 // ----------------------------------------------------------------------------------------
 struct GactLds {
-    uint32_t tb_words;     // dwords of traceback per lane
+    uint32_t tb_words;     // dwords of traceback per lane (only anti-diagonals a walk can reach)
     uint32_t seq_bytes;    // bytes of one staged sequence incl. both pads
     uint32_t ops_bytes;
     uint32_t wave_bytes;   // total per wavefront
 };
 
-__host__ __device__ inline GactLds gact_lds_layout(int T) {
+__host__ __device__ inline GactLds gact_lds_layout(int T, int O) {
     GactLds g;
-    g.tb_words = (uint32_t) (2 * T) / 16 + 1;
+    const uint32_t cap2 = 2u * (uint32_t) (T - O);            // a walk never reads a pointer at s >= 2(T-O)
+    g.tb_words = ((cap2 - 1) >> 4) + 1;
     g.seq_bytes = ((uint32_t) T + 2 * GACT_PAD + 15u) & ~15u;
-    g.ops_bytes = ((uint32_t) (2 * T) + 15u) & ~15u;
+    g.ops_bytes = (cap2 + 15u) & ~15u;
     g.wave_bytes = g.tb_words * 64 * 4 + 2 * g.seq_bytes + g.ops_bytes;
     return g;
 }
@@ -115,22 +116,24 @@ __device__ __forceinline__ int dpp_from_upper(int v, int fill) {   // lane L <- 
     return __builtin_amdgcn_update_dpp(fill, v, DPP_WAVE_SHL1, 0xf, 0xf, false);
 }
 
-// one DP step for this lane's lattice point; returns new R, appends the 2-bit pointer to acc
+// one DP step for this lane's lattice point.  TRACK: also append the 2-bit pointer to acc.
+template <bool TRACK, bool FULLBAND>
 __device__ __forceinline__ int gact_cell(int r_diag, int r_ins, int r_del, uint32_t qc, uint32_t dc,
                                          bool is_exit, bool inband, uint32_t &acc) {
     int cd = r_diag + (qc == dc ? 1 : -1);
-    int ci = r_ins - 1, cl = r_del - 1;
-    int m1 = ci >= cl ? ci : cl;
-    uint32_t p1 = ci >= cl ? 1u : 2u;          // INS before DEL on ties
-    bool diag = cd >= m1;                      // DIAG wins ties
-    int best = diag ? cd : m1;
-    uint32_t p = diag ? 0u : p1;
+    int m1 = (r_ins >= r_del ? r_ins : r_del) - 1;
+    int best = cd >= m1 ? cd : m1;
+    if (TRACK) {
+        uint32_t p1 = r_ins >= r_del ? 1u : 2u;        // INS before DEL on ties
+        uint32_t p = cd >= m1 ? 0u : p1;               // DIAG wins ties
+        acc = (acc << 2) | p;
+    }
     best = is_exit ? 0 : best;
-    best = inband ? best : GACT_NEG;
-    acc = (acc << 2) | p;
+    if (!FULLBAND) best = inband ? best : GACT_NEG;
     return best;
 }
 
+template <bool FULLBAND>
 __global__ __launch_bounds__(256) void gact_kernel(const char *__restrict__ reads, uint64_t stride,
                                                    const uint32_t *__restrict__ lens,
                                                    const lrm_seq_meta *__restrict__ meta,
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void gact_kernel(const char *__restrict__ read
         if (lane == 0) { n_ops_out[read] = 0; score_out[read] = -1; }
         return;
     }
-    const GactLds L = gact_lds_layout(T);
+    const GactLds L = gact_lds_layout(T, O);
     uint8_t *base = smem + (size_t) wave * L.wave_bytes;
     uint32_t *tb = reinterpret_cast<uint32_t *>(base);
     uint8_t *qbuf = base + (size_t) L.tb_words * 256 + GACT_PAD;
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(256) void gact_kernel(const char *__restrict__ read
     const int dE = 2 * lane - 64, dO = 2 * lane - 63;
     const bool inE = dE >= -hw && dE < hw, inO = dO >= -hw && dO < hw;
     const int cap = T - O;
+    const int s_hi = (int) L.tb_words * 16 - 1;                  // highest anti-diagonal whose pointers are kept
 
     int i = 0, j = 0, nops = 0, score = 0;
     unsigned tiles = 0;
@@ -185,47 +189,59 @@ __global__ __launch_bounds__(256) void gact_kernel(const char *__restrict__ read
         int r1 = GACT_NEG, r2 = GACT_NEG;                        // R at s+1 and s+2 for this lane
         uint32_t acc = 0;
         int s = tq + tt;
-        // per-lane coordinates at the current step
-        uint32_t qc = 0, dc = 0;
-        if ((s & 1) == 0) {
-            // even head step: a = s/2+32-lane, b = s/2-32+lane
-            int a = s / 2 + 32 - lane, b = s / 2 - 32 + lane;
-            qc = qbuf[a]; dc = dbuf[b];
-            int ins = dpp_from_lower(r1, GACT_NEG);
-            int r0 = gact_cell(r2, ins, r1, qc, dc, s >= eE, inE, acc);
-            r2 = r1; r1 = r0;
-            if ((s & 15) == 0) { tb[(s >> 4) * 64 + lane] = acc; }
+        // Per-lane sequence cursors.  Odd steps move one query base down (a--), even steps one
+        // target base down (b--); the base needed by the NEXT step of each kind is prefetched so
+        // the LDS latency sits under a whole step pair.
+        const uint8_t *qp, *dp;
+        uint32_t qc = 0, dc = 0, qn, dn;
+        if ((s & 1) == 0) {          // first step is even: a = s/2+32-lane is current, b steps down into s/2-32+lane
+            qp = qbuf + (s / 2 + 32 - lane);
+            dp = dbuf + (s / 2 - 32 + lane) + 1;
+            qc = *qp;
+        } else {                     // first step is odd: b = (s-1)/2-31+lane is current, a steps down into (s-1)/2+32-lane
+            qp = qbuf + ((s - 1) / 2 + 32 - lane) + 1;
+            dp = dbuf + ((s - 1) / 2 - 31 + lane);
+            dc = *dp;
+        }
+        qn = qp[-1];
+        dn = dp[-1];
+
+#define GACT_ODD(TRACK, S) do {                                                        \
+            qc = qn; qp -= 1; qn = qp[-1];                                                 \
+            int del_ = dpp_from_upper(r1, GACT_NEG);                                       \
+            int r0_ = gact_cell<TRACK, FULLBAND>(r2, r1, del_, qc, dc, (S) >= eO, inO, acc); \
+            r2 = r1; r1 = r0_;                                                             \
+        } while (0)
+#define GACT_EVEN(TRACK, S) do {                                                       \
+            dc = dn; dp -= 1; dn = dp[-1];                                                 \
+            int ins_ = dpp_from_lower(r1, GACT_NEG);                                       \
+            int r0_ = gact_cell<TRACK, FULLBAND>(r2, ins_, r1, qc, dc, (S) >= eE, inE, acc); \
+            r2 = r1; r1 = r0_;                                                             \
+        } while (0)
+
+        // phase A: anti-diagonals no walk can reach -- scores only
+        if (s > s_hi && (s & 1) == 0) { GACT_EVEN(false, s); s--; }
+        for (; s - 1 > s_hi; s -= 2) { GACT_ODD(false, s); GACT_EVEN(false, s - 1); }
+        if (s > s_hi) { GACT_ODD(false, s); s--; }
+        // phase B: scores + traceback pointers, 16 steps per dword
+        if (s >= 0 && (s & 1) == 0) {
+            GACT_EVEN(true, s);
+            if ((s & 15) == 0) tb[(s >> 4) * 64 + lane] = acc;
             s--;
-        } else {
-            // prime chars for the odd/even pair loop: the odd step reloads qc, keeps dc
-            int b = (s - 1) / 2 - 31 + lane;                     // b at odd s
-            dc = dbuf[b];
         }
-        // pair loop: odd step s, then even step s-1
         for (; s >= 1; s -= 2) {
-            {   // odd: a = (s-1)/2+32-lane (decremented), b unchanged
-                int a = (s - 1) / 2 + 32 - lane;
-                qc = qbuf[a];
-                int del = dpp_from_upper(r1, GACT_NEG);
-                int r0 = gact_cell(r2, r1, del, qc, dc, s >= eO, inO, acc);
-                r2 = r1; r1 = r0;
-            }
-            {   // even: s-1; b = (s-1)/2-32+lane (decremented), a unchanged
-                int se = s - 1;
-                int b = se / 2 - 32 + lane;
-                dc = dbuf[b];
-                int ins = dpp_from_lower(r1, GACT_NEG);
-                int r0 = gact_cell(r2, ins, r1, qc, dc, se >= eE, inE, acc);
-                r2 = r1; r1 = r0;
-                if ((se & 15) == 0) { tb[(se >> 4) * 64 + lane] = acc; }
-            }
+            GACT_ODD(true, s);
+            GACT_EVEN(true, s - 1);
+            if (((s - 1) & 15) == 0) tb[((s - 1) >> 4) * 64 + lane] = acc;
         }
+#undef GACT_ODD
+#undef GACT_EVEN
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
         // traceback walk from the anchor (uniform across the wavefront)
         int a = 0, b = 0, cnt = 0;
-        while (a < tq && b < tt && (last || (a < cap && b < cap))) {
+        while (a < tq && b < tt && (last ? (a + b < 2 * cap) : (a < cap && b < cap))) {
             int sw = a + b, dd = b - a;
             uint32_t word = tb[(sw >> 4) * 64 + ((dd + 64) >> 1)];
             uint32_t p = (word >> (2 * (sw & 15))) & 3u;
@@ -267,6 +283,28 @@ __global__ __launch_bounds__(256) void gact_kernel(const char *__restrict__ read
     }
 }
 
+typedef void (*gact_fn_t)(const char *, uint64_t, const uint32_t *, const lrm_seq_meta *, const int32_t *,
+                          const char *, const uint32_t *, uint64_t, int, int, int, uint8_t *, uint64_t, int32_t *,
+                          int32_t *, LrmDevCounters *);
+
+static int gact_launch(lrm_gact_params gp, uint64_t n, hipStream_t stream, const char *reads, uint64_t stride,
+                       const uint32_t *lens, const lrm_seq_meta *meta, const int32_t *meta_r, const char *content,
+                       const uint32_t *tlens, uint8_t *store, uint64_t store_stride, int32_t *n_ops, int32_t *score,
+                       LrmDevCounters *counters) {
+    GactLds L = gact_lds_layout(gp.T, gp.O);
+    size_t shmem = (size_t) L.wave_bytes * 4;
+    gact_fn_t fn = gp.W >= 128 ? gact_kernel<true> : gact_kernel<false>;
+    if (shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        if (e != hipSuccess) { lrm_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", shmem, hipGetErrorString(e)); return -1; }
+    }
+    uint64_t blocks = (n + 3) / 4;
+    hipLaunchKernelGGL(fn, dim3((uint32_t) blocks), dim3(256), shmem, stream, reads, stride, lens, meta, meta_r,
+                       content, tlens, n, gp.T, gp.O, gp.W, store, store_stride, n_ops, score, counters);
+    return 0;
+}
+
 // ----------------------------------------------------------------------------------------
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     lrm_set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
@@ -290,31 +328,24 @@ int lrm_launch_extend(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint64_t
         lrm_set_error("store_stride %llu < 2*max_len %u", (unsigned long long) store_stride, max_len);
         return -1;
     }
+    lrm_time_begin(ws, LRM_K_LOCUS, stream);
     hipLaunchKernelGGL(locus_resolve_kernel, dim3((uint32_t) ((n + 255) / 256)), dim3(256), 0, stream,
                        idx->view, d_best, d_lens, n, d_meta, d_meta_r);
+    lrm_time_end(ws, stream);
     {
         uint32_t cpr = ((max_len + 1) / 2 + 255) / 256;
         if (cpr == 0) cpr = 1;
         uint64_t blocks = n * cpr;
         if (blocks > 0x7fffffffull) { lrm_set_error("revcomp grid too large: split the batch"); return -1; }
+        lrm_time_begin(ws, LRM_K_REVCOMP, stream);
         hipLaunchKernelGGL(revcomp_kernel, dim3((uint32_t) blocks), dim3(256), 0, stream, d_reads, stride,
                            d_lens, d_meta, d_meta_r, n, cpr);
+        lrm_time_end(ws, stream);
     }
-    {
-        GactLds L = gact_lds_layout(gp.T);
-        size_t shmem = (size_t) L.wave_bytes * 4;
-        static size_t configured = 0;
-        if (shmem > 64 * 1024 && shmem > configured) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gact_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem));
-            configured = shmem;
-        }
-        uint64_t blocks = (n + 3) / 4;
-        hipLaunchKernelGGL(gact_kernel, dim3((uint32_t) blocks), dim3(256), shmem, stream, d_reads, stride,
-                           d_lens, d_meta, d_meta_r, idx->view.content, (const uint32_t *) nullptr, n, gp.T, gp.O,
-                           gp.W, d_store,
-                           store_stride, d_n_ops, d_score, ws->d_counters);
-    }
+    lrm_time_begin(ws, LRM_K_GACT, stream);
+    if (gact_launch(gp, n, stream, d_reads, stride, d_lens, d_meta, d_meta_r, idx->view.content,
+                    (const uint32_t *) nullptr, d_store, store_stride, d_n_ops, d_score, ws->d_counters)) return -1;
+    lrm_time_end(ws, stream);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -358,13 +389,7 @@ extern "C" int lrm_debug_gact(const char *q, int n, const char *d, int m, lrm_ga
     HIPCHK(hipMemcpy(dl, hl, 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dm, &hm, sizeof(hm), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dr, hr, 12, hipMemcpyHostToDevice));
-    GactLds L = gact_lds_layout(gp.T);
-    size_t shmem = (size_t) L.wave_bytes * 4;
-    if (shmem > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gact_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem));
-    hipLaunchKernelGGL(gact_kernel, dim3(1), dim3(256), shmem, 0, dq, (uint64_t) 0, dl, dm, dr, dd, dl + 1,
-                       (uint64_t) 1, gp.T, gp.O, gp.W, dops, (uint64_t) 0, dr + 1, dr + 2, dc);
+    if (gact_launch(gp, 1, 0, dq, 0, dl, dm, dr, dd, dl + 1, dops, 0, dr + 1, dr + 2, dc)) return -1;
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(hr, dr, 12, hipMemcpyDeviceToHost));

@@ -225,7 +225,11 @@ extern "C" void lrm_workspace_free(lrm_workspace *ws) {
     if (!ws) return;
     (void) hipSetDevice(ws->device);
     (void) hipFree(ws->d_reads2); (void) hipFree(ws->d_rec); (void) hipFree(ws->d_phase); (void) hipFree(ws->d_decided);
-    (void) hipFree(ws->d_ovf_items); (void) hipFree(ws->d_ovf_tables); (void) hipFree(ws->d_counters);
+    (void) hipFree(ws->d_ovf_items); (void) hipFree(ws->d_ovf_items2); (void) hipFree(ws->d_counters);
+    for (int i = 0; i < LRM_MAX_TIMED; ++i) {
+        if (ws->ev_start[i]) (void) hipEventDestroy((hipEvent_t) ws->ev_start[i]);
+        if (ws->ev_stop[i]) (void) hipEventDestroy((hipEvent_t) ws->ev_stop[i]);
+    }
     delete ws;
 }
 
@@ -248,18 +252,13 @@ extern "C" int lrm_workspace_create(lrm_workspace **out, lrm_index *idx, uint64_
     ws->cap_q = (jl + ws->P - 1) / ws->P;
     if (ws->cap_q == 0) ws->cap_q = 1;
     ws->words_per_read = (uint64_t) max_len / 32 + 2;
-    ws->ovf_slots = 32;
-    uint64_t need = 2ull * ws->cap_q * (uint64_t) (thres > 1 ? thres - 1 : 1);
-    uint64_t cap = 1024;
-    while (cap < need && cap < (1ull << 22)) cap <<= 1;
-    ws->ovf_cap = cap;
     struct { void **p; uint64_t bytes; } allocs[] = {
         {(void **) &ws->d_reads2, n_max * ws->words_per_read * 8},
         {(void **) &ws->d_rec, n_max * (uint64_t) ws->P * ws->cap_q * 8},
         {(void **) &ws->d_phase, n_max * (uint64_t) ws->P * sizeof(LrmPhaseRes)},
         {(void **) &ws->d_decided, n_max},
         {(void **) &ws->d_ovf_items, n_max * (uint64_t) ws->P * 8},
-        {(void **) &ws->d_ovf_tables, ws->ovf_slots * ws->ovf_cap * 32},
+        {(void **) &ws->d_ovf_items2, n_max * (uint64_t) ws->P * 8},
         {(void **) &ws->d_counters, sizeof(LrmDevCounters)},
     };
     for (auto &a : allocs) {
@@ -316,11 +315,61 @@ extern "C" int lrm_workspace_stats(lrm_workspace *ws, lrm_stats *out, void *stre
     LrmDevCounters c;
     HIPCHK(hipMemcpyAsync(&c, ws->d_counters, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t) stream));
     HIPCHK(hipStreamSynchronize((hipStream_t) stream));
-    out->vote_overflow_items = c.overflow_n[0] + c.overflow_n[1];
+    out->vote_tier2_items = c.tier_n[0][0] + c.tier_n[1][0];
+    out->vote_tier3_items = c.tier_n[0][1] + c.tier_n[1][1];
     out->reads_decided_phase0 = c.decided_phase0;
     out->gact_tiles = c.gact_tiles;
-    if (c.error_flags & 1ull) { lrm_set_error("vote fallback table capacity exceeded: results of some phases are invalid"); return -2; }
+    if (c.error_flags & 1ull) { lrm_set_error("vote table overflow in the multi-pass tier: results of some phases are invalid"); return -2; }
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-kernel timing
+// ------------------------------------------------------------------------------------------
+void lrm_time_begin(lrm_workspace *ws, int kernel, void *stream) {
+    if (!ws || !ws->timing || ws->n_timed >= LRM_MAX_TIMED) return;
+    int i = ws->n_timed;
+    if (!ws->ev_start[i]) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        ws->ev_start[i] = a; ws->ev_stop[i] = b;
+    }
+    ws->ev_kernel[i] = kernel;
+    (void) hipEventRecord((hipEvent_t) ws->ev_start[i], (hipStream_t) stream);
+}
+
+void lrm_time_end(lrm_workspace *ws, void *stream) {
+    if (!ws || !ws->timing || ws->n_timed >= LRM_MAX_TIMED || !ws->ev_stop[ws->n_timed]) return;
+    (void) hipEventRecord((hipEvent_t) ws->ev_stop[ws->n_timed], (hipStream_t) stream);
+    ws->n_timed++;
+}
+
+extern "C" int lrm_workspace_set_timing(lrm_workspace *ws, int enable) {
+    if (!ws) { lrm_set_error("null argument"); return -1; }
+    ws->timing = enable ? 1 : 0;
+    ws->n_timed = 0;
+    return 0;
+}
+
+extern "C" int lrm_workspace_timing(lrm_workspace *ws, double *ms, uint64_t *launches, void *stream) {
+    if (!ws || !ms || !launches) { lrm_set_error("null argument"); return -1; }
+    HIPCHK(hipSetDevice(ws->device));
+    HIPCHK(hipStreamSynchronize((hipStream_t) stream));
+    for (int i = 0; i < ws->n_timed; ++i) {
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, (hipEvent_t) ws->ev_start[i], (hipEvent_t) ws->ev_stop[i]));
+        ms[ws->ev_kernel[i]] += (double) t;
+        launches[ws->ev_kernel[i]] += 1;
+    }
+    ws->n_timed = 0;
+    return 0;
+}
+
+extern "C" const char *lrm_kernel_name(int k) {
+    static const char *names[LRM_K_COUNT] = {"pack2bit_kernel", "seed_search_kernel", "vote_kernel",
+                                             "vote_fallback_kernel", "decide_kernel", "locus_resolve_kernel",
+                                             "revcomp_kernel", "gact_kernel"};
+    return k >= 0 && k < LRM_K_COUNT ? names[k] : "?";
 }
 
 // ------------------------------------------------------------------------------------------

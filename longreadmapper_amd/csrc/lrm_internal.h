@@ -79,16 +79,25 @@ struct LrmPhaseRes {
 
 // Device counters block (one per workspace).
 struct LrmDevCounters {
-    unsigned long long overflow_n[2];    // per launch round: (read,phase) items in the overflow list
-    unsigned long long overflow_done[2]; // per launch round: work-queue head of the fallback kernel
+    unsigned long long tier_n[2][2];     // [launch round][tier 2 / tier 3]: items pushed to that tier
+    unsigned long long tier_head[2][2];  // work-queue heads of the workgroup-tier kernels
     unsigned long long decided_phase0;
     unsigned long long gact_tiles;
-    unsigned long long error_flags;      // bit0: fallback table capacity exceeded
+    unsigned long long error_flags;
     unsigned long long pad;
 };
 
+enum LrmKernelId { LRM_K_PACK2BIT = 0, LRM_K_SEED_SEARCH, LRM_K_VOTE, LRM_K_VOTE_FALLBACK, LRM_K_DECIDE,
+                   LRM_K_LOCUS, LRM_K_REVCOMP, LRM_K_GACT, LRM_K_COUNT };
+#define LRM_MAX_TIMED 4096
+
 struct lrm_workspace {
     lrm_index *idx;
+    // optional per-kernel timing (HIP events recorded on the launch stream)
+    int timing;
+    int n_timed;
+    void *ev_start[LRM_MAX_TIMED], *ev_stop[LRM_MAX_TIMED];
+    int ev_kernel[LRM_MAX_TIMED];
     int device;
     uint64_t n_max;
     uint32_t max_len, seed_len, thres;
@@ -101,13 +110,14 @@ struct lrm_workspace {
     uint64_t *d_rec;         // per-seed records: n_max * P * cap_q
     LrmPhaseRes *d_phase;    // n_max * P
     uint8_t *d_decided;      // n_max
-    uint64_t *d_ovf_items;   // overflow items (read*P+iter): round 0 at [0,n_max), round 1 after
-    void *d_ovf_tables;      // fallback vote tables (global memory)
-    uint64_t ovf_slots, ovf_cap;   // concurrent fallback blocks, entries per table
+    uint64_t *d_ovf_items;   // tier-2 item list (read*P+iter): round 0 at [0,n_max), round 1 after
+    uint64_t *d_ovf_items2;  // tier-3 item list, same layout
     LrmDevCounters *d_counters;
 };
 
 void lrm_set_error(const char *fmt, ...);
+void lrm_time_begin(lrm_workspace *ws, int kernel, void *stream);
+void lrm_time_end(lrm_workspace *ws, void *stream);
 
 // launchers implemented in the .hip files (all asynchronous on `stream`)
 int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint64_t stride,

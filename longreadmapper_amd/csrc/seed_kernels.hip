@@ -17,8 +17,6 @@
 #include <hip/hip_runtime.h>
 #include "lrm_internal.h"
 
-#define VOTE_SLOTS 256           // LDS vote-table slots per wavefront
-#define VOTE_MAX_PROBE 48
 #define EMPTY64 0xFFFFFFFFFFFFFFFFull
 
 // A/a=0 C/c=1 G/g=2 T/t=3 ; other bytes are fenced (UB in the reference, lchash.c:38-44)
@@ -187,24 +185,41 @@ __global__ __launch_bounds__(256) void seed_search_debug_kernel(LrmIndexView ix,
 }
 
 // ----------------------------------------------------------------------------------------
-// K2 vote: one wavefront per (read, phase).
-// histo_add / histo_find_2_max (histo.c:42-56, 84-96) order entries by insertion; the
-// stable top-2 is "val descending, first-seen ascending".  First-seen order of a bucket is
-// the order of (seed ordinal q, SA offset t) of its first hit, which is intrinsic to the hit,
-// so the table can be filled in any order: every slot keeps count, min key, min (q,t).
+// K2 vote.
+// histo_add / histo_find_2_max (histo.c:42-56, 84-96) order entries by insertion; the stable
+// top-2 is "val descending, first-seen ascending".  First-seen order of a bucket is the order of
+// (seed ordinal q, SA offset t) of its first hit = the index h of that hit in the phase's
+// flattened hit list, which is intrinsic to the hit -- so the table can be filled in any order:
+// every slot keeps the count, the low 4 bits of the minimum key and the minimum h.
+//
+// The vote table always lives in LDS.  Items ((read, phase) pairs) are tiered by their hit count
+// H = sum of rr, an upper bound on the distinct buckets:
+//   tier 1  H <= 192          one wavefront per item, 256 slots, 4 items per workgroup
+//   tier 2  H <= T2_LIMIT     one 256-thread workgroup per item, 2048 slots
+//   tier 3  any H             one workgroup per item, 3072 slots, ceil(H/limit) passes: pass p only
+//                             admits buckets with hash % passes == p, the per-pass top-2 are merged
+//                             (buckets of different passes are disjoint, so the merge is exact)
+// A tier that finds H above its limit pushes the item to the next tier's list.
 // ----------------------------------------------------------------------------------------
-struct Cand { uint32_t val; uint32_t slot; uint64_t seq; };
+#define T1_SLOTS 256
+#define T1_LIMIT 192
+#define T2_SLOTS 2048
+#define T2_LIMIT 1536
+#define T3_SLOTS 3072
+#define T3_LIMIT 2304
+#define EMPTY32 0xFFFFFFFFu
+
+struct Cand { uint32_t val; uint32_t first; uint32_t slot; };
 
 __device__ __forceinline__ bool better(const Cand &a, const Cand &b) {
-    return a.val > b.val || (a.val == b.val && a.seq < b.seq);
+    return a.val > b.val || (a.val == b.val && a.first < b.first);
 }
 
 __device__ __forceinline__ Cand shfl_xor_cand(const Cand &c, int m) {
     Cand o;
     o.val = __shfl_xor(c.val, m);
+    o.first = __shfl_xor(c.first, m);
     o.slot = __shfl_xor(c.slot, m);
-    uint32_t lo = __shfl_xor((uint32_t) c.seq, m), hi = __shfl_xor((uint32_t) (c.seq >> 32), m);
-    o.seq = ((uint64_t) hi << 32) | lo;
     return o;
 }
 
@@ -222,17 +237,54 @@ __device__ __forceinline__ uint32_t phase_count(uint32_t jl, uint32_t iter, uint
     return jl > iter ? (jl - iter + P - 1) / P : 0;
 }
 
-__global__ __launch_bounds__(256) void vote_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
-                                                   const uint32_t *__restrict__ lens,
-                                                   const uint8_t *__restrict__ decided, uint64_t n,
-                                                   int seed_len, int phase_lo, int phase_hi, uint32_t cap_q,
-                                                   LrmPhaseRes *__restrict__ phase_res,
-                                                   uint64_t *__restrict__ ovf_items, LrmDevCounters *counters,
-                                                   int round) {
-    __shared__ uint64_t s_bucket[4][VOTE_SLOTS];
-    __shared__ uint64_t s_minkey[4][VOTE_SLOTS];
-    __shared__ uint64_t s_seq[4][VOTE_SLOTS];
-    __shared__ uint32_t s_count[4][VOTE_SLOTS];
+__device__ __forceinline__ uint32_t bucket_hash(uint64_t bucket) {
+    return (uint32_t) ((bucket * 0x9E3779B97F4A7C15ull) >> 32);
+}
+
+struct VoteTable {
+    uint64_t *bucket;
+    uint32_t *count, *first, *minlow;
+    uint32_t slots;
+};
+
+// Returns false only if the table is full (never for tiers 1/2, where H <= 0.75*slots; in the
+// multi-pass tier only under a pathological hash skew) -- the probe loop is bounded so a wave can
+// never spin.
+__device__ __forceinline__ bool vote_insert(const VoteTable &t, uint64_t key, uint32_t h, uint32_t hash) {
+    const uint64_t bucket = key >> 4;                                   // histo.c:26-28
+    uint32_t slot = (uint32_t) (((uint64_t) hash * t.slots) >> 32);
+    for (uint32_t probe = 0; probe < t.slots; ++probe) {
+        unsigned long long prev = atomicCAS((unsigned long long *) &t.bucket[slot], EMPTY64, bucket);
+        if (prev == EMPTY64 || prev == bucket) {
+            atomicAdd(&t.count[slot], 1u);
+            atomicMin(&t.minlow[slot], (uint32_t) (key & 15));
+            atomicMin(&t.first[slot], h);
+            return true;
+        }
+        slot = slot + 1 == t.slots ? 0 : slot + 1;
+    }
+    return false;
+}
+
+struct PhaseTop { uint64_t key1, bucket1, key2, bucket2; uint32_t val1, first1, val2, first2; };
+
+__device__ __forceinline__ void write_phase(LrmPhaseRes *out, const PhaseTop &p) {
+    LrmPhaseRes res = {0, 0, 0, 0, 0, 0};
+    if (p.val1) { res.key1 = p.key1; res.val1 = p.val1; res.bucket1 = p.bucket1; }
+    if (p.val2) { res.key2 = p.key2; res.val2 = p.val2; res.bucket2 = p.bucket2; }
+    *out = res;
+}
+
+// ---- tier 1: one wavefront per item ---------------------------------------------------------
+__global__ __launch_bounds__(256) void vote_wave_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
+                                                        const uint32_t *__restrict__ lens,
+                                                        const uint8_t *__restrict__ decided, uint64_t n,
+                                                        int seed_len, int phase_lo, int phase_hi, uint32_t cap_q,
+                                                        LrmPhaseRes *__restrict__ phase_res,
+                                                        uint64_t *__restrict__ next_items,
+                                                        unsigned long long *next_n) {
+    __shared__ uint64_t s_bucket[4][T1_SLOTS];
+    __shared__ uint32_t s_count[4][T1_SLOTS], s_first[4][T1_SLOTS], s_minlow[4][T1_SLOTS];
     __shared__ uint32_t s_incl[4][64];
     __shared__ uint64_t s_k[4][64];
 
@@ -245,90 +297,75 @@ __global__ __launch_bounds__(256) void vote_kernel(LrmIndexView ix, const uint64
     int iter = phase_lo + (int) (item % (uint64_t) np);
     if (decided && decided[read]) return;
 
-    uint64_t *tb = s_bucket[wave];
-    uint64_t *tk = s_minkey[wave];
-    uint64_t *ts = s_seq[wave];
-    uint32_t *tc = s_count[wave];
+    uint32_t len = lens[read];
+    uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;
+    uint32_t cnt = phase_count(jl, (uint32_t) iter, (uint32_t) P);
+    const uint64_t id = read * (uint64_t) P + (uint64_t) iter;
+    const uint64_t *r = rec + id * cap_q;
+
+    // hit count of the phase (upper bound on distinct buckets)
+    uint32_t my = 0;
+    for (uint32_t q = lane; q < cnt; q += 64) my += (uint32_t) (r[q] >> 40);
 #pragma unroll
-    for (int t = 0; t < VOTE_SLOTS / 64; ++t) {
-        int s = lane + 64 * t;
-        tb[s] = EMPTY64; tk[s] = EMPTY64; ts[s] = EMPTY64; tc[s] = 0;
+    for (int m = 1; m < 64; m <<= 1) my += __shfl_xor(my, m);
+    const uint32_t H = my;
+    if (H == 0) {
+        if (lane == 0) { LrmPhaseRes z = {0, 0, 0, 0, 0, 0}; phase_res[id] = z; }
+        return;
+    }
+    if (H > T1_LIMIT) {
+        if (lane == 0) next_items[atomicAdd(next_n, 1ull)] = id;
+        return;
+    }
+    VoteTable t = {s_bucket[wave], s_count[wave], s_first[wave], s_minlow[wave], T1_SLOTS};
+#pragma unroll
+    for (int x = 0; x < T1_SLOTS / 64; ++x) {
+        int s = lane + 64 * x;
+        t.bucket[s] = EMPTY64; t.count[s] = 0; t.first[s] = EMPTY32; t.minlow[s] = EMPTY32;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    uint32_t len = lens[read];
-    uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;
-    uint32_t cnt = phase_count(jl, (uint32_t) iter, (uint32_t) P);
-    const uint64_t *r = rec + (read * (uint64_t) P + (uint64_t) iter) * cap_q;
-    bool overflow = false;
-
+    uint32_t hbase = 0;
     for (uint32_t q0 = 0; q0 < cnt; q0 += 64) {
         uint32_t q = q0 + lane;
         uint64_t e = q < cnt ? r[q] : 0ull;
         uint32_t rr = (uint32_t) (e >> 40);
-        uint64_t k = e & ((1ull << 40) - 1ull);
-        // inclusive scan of rr over the wavefront
         uint32_t incl = rr;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            uint32_t t = __shfl_up(incl, d);
-            if (lane >= d) incl += t;
+            uint32_t v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
         }
         uint32_t total = __shfl(incl, 63);
         if (total == 0) continue;
         s_incl[wave][lane] = incl;
-        s_k[wave][lane] = k;
+        s_k[wave][lane] = e & ((1ull << 40) - 1ull);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (uint32_t h = lane; h < total; h += 64) {
-            // owner = first lane whose inclusive sum exceeds h
-            int lo = 0, hi = 63;
+            int lo = 0, hi = 63;                 // owner = first lane whose inclusive sum exceeds h
             while (lo < hi) {
                 int mid = (lo + hi) >> 1;
                 if (s_incl[wave][mid] > h) hi = mid; else lo = mid + 1;
             }
             uint32_t owner = (uint32_t) lo;
-            uint32_t excl = owner ? s_incl[wave][owner - 1] : 0;
-            uint32_t t = h - excl;
-            uint64_t kk = s_k[wave][owner];
+            uint32_t tt = h - (owner ? s_incl[wave][owner - 1] : 0);
             uint64_t jq = (uint64_t) iter + (uint64_t) (q0 + owner) * (uint64_t) P;
-            uint64_t key = ix.sa[kk + t] - jq;                     // alnmain.c:363-365 (u64 wrap kept)
-            uint64_t bucket = key >> 4;                            // histo.c:26-28
-            uint64_t seq = ((uint64_t) (q0 + owner) << 32) | t;
-            uint32_t slot = (uint32_t) ((bucket * 0x9E3779B97F4A7C15ull) >> 56) & (VOTE_SLOTS - 1);
-            bool done = false;
-            for (int probe = 0; probe < VOTE_MAX_PROBE; ++probe) {
-                unsigned long long prev = atomicCAS((unsigned long long *) &tb[slot], EMPTY64, bucket);
-                if (prev == EMPTY64 || prev == bucket) {
-                    atomicAdd(&tc[slot], 1u);
-                    atomicMin((unsigned long long *) &tk[slot], key);
-                    atomicMin((unsigned long long *) &ts[slot], seq);
-                    done = true;
-                    break;
-                }
-                slot = (slot + 1) & (VOTE_SLOTS - 1);
-            }
-            if (!done) overflow = true;
+            uint64_t key = ix.sa[s_k[wave][owner] + tt] - jq;          // alnmain.c:363-365 (u64 wrap kept)
+            vote_insert(t, key, hbase + h, bucket_hash(key >> 4));
         }
+        hbase += total;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-
-    if (__any(overflow)) {
-        if (lane == 0) {
-            unsigned long long pos = atomicAdd(&counters->overflow_n[round], 1ull);
-            ovf_items[pos] = read * (uint64_t) P + (uint64_t) iter;
-        }
-        return;
-    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    Cand b1 = {0u, 0u, EMPTY64}, b2 = {0u, 0u, EMPTY64};
+    Cand b1 = {0u, EMPTY32, 0u}, b2 = {0u, EMPTY32, 0u};
 #pragma unroll
-    for (int t = 0; t < VOTE_SLOTS / 64; ++t) {
-        int s = lane + 64 * t;
-        Cand c = {tc[s], (uint32_t) s, ts[s]};
+    for (int x = 0; x < T1_SLOTS / 64; ++x) {
+        int s = lane + 64 * x;
+        Cand c = {t.count[s], t.first[s], (uint32_t) s};
         if (better(c, b1)) { b2 = b1; b1 = c; }
         else if (better(c, b2)) b2 = c;
     }
@@ -338,130 +375,148 @@ __global__ __launch_bounds__(256) void vote_kernel(LrmIndexView ix, const uint64
         merge_top2(b1, b2, o1, o2);
     }
     if (lane == 0) {
-        LrmPhaseRes res = {0, 0, 0, 0, 0, 0};
-        if (b1.val) { res.key1 = tk[b1.slot]; res.val1 = b1.val; res.bucket1 = tb[b1.slot]; }
-        if (b2.val) { res.key2 = tk[b2.slot]; res.val2 = b2.val; res.bucket2 = tb[b2.slot]; }
-        phase_res[read * (uint64_t) P + (uint64_t) iter] = res;
+        PhaseTop p = {};
+        if (b1.val) { p.val1 = b1.val; p.bucket1 = t.bucket[b1.slot]; p.key1 = (p.bucket1 << 4) | t.minlow[b1.slot]; }
+        if (b2.val) { p.val2 = b2.val; p.bucket2 = t.bucket[b2.slot]; p.key2 = (p.bucket2 << 4) | t.minlow[b2.slot]; }
+        write_phase(&phase_res[id], p);
     }
 }
 
-// ----------------------------------------------------------------------------------------
-// vote_fallback: phases whose distinct buckets do not fit the LDS table.  One 256-thread
-// workgroup per item, vote table in global memory sized from the item's own hit count.
-// Rare path (repeat-dense loci); correctness first.
-// ----------------------------------------------------------------------------------------
-struct GEntry { unsigned long long bucket, minkey, seq; unsigned int count, pad; };
-
-__global__ __launch_bounds__(256) void vote_fallback_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
-                                                            const uint32_t *__restrict__ lens, int seed_len,
-                                                            uint32_t cap_q, LrmPhaseRes *__restrict__ phase_res,
-                                                            const uint64_t *__restrict__ ovf_items,
-                                                            LrmDevCounters *counters, GEntry *tables,
-                                                            uint64_t table_cap, int round) {
+// ---- tiers 2 and 3: one 256-thread workgroup per item, persistent grid over an item list -----
+__global__ __launch_bounds__(256) void vote_block_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
+                                                         const uint32_t *__restrict__ lens, int seed_len,
+                                                         uint32_t cap_q, LrmPhaseRes *__restrict__ phase_res,
+                                                         const uint64_t *__restrict__ items,
+                                                         const unsigned long long *n_items_p,
+                                                         unsigned long long *head, uint32_t slots, uint32_t limit,
+                                                         int multipass, uint64_t *__restrict__ next_items,
+                                                         unsigned long long *next_n,
+                                                         unsigned long long *err_flags) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t vsmem[];
     __shared__ unsigned long long s_item;
-    __shared__ unsigned long long s_hits;
-    __shared__ Cand s_c1[256], s_c2[256];
+    __shared__ uint32_t s_incl[256];
+    __shared__ uint64_t s_k[256];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ Cand s_c1[4], s_c2[4];
+    __shared__ uint32_t s_H;
+
+    VoteTable t;
+    t.slots = slots;
+    t.bucket = reinterpret_cast<uint64_t *>(vsmem);
+    t.count = reinterpret_cast<uint32_t *>(vsmem + (size_t) slots * 8);
+    t.first = t.count + slots;
+    t.minlow = t.first + slots;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int P = seed_len + 1;
-    GEntry *tab = tables + (uint64_t) blockIdx.x * table_cap;
-    const unsigned long long n_items = counters->overflow_n[round];
+    const unsigned long long n_items = *n_items_p;
 
     while (true) {
-        if (threadIdx.x == 0) {
-            s_item = atomicAdd(&counters->overflow_done[round], 1ull);
-            s_hits = 0;
-        }
+        if (tid == 0) { s_item = atomicAdd(head, 1ull); s_H = 0; }
         __syncthreads();
-        unsigned long long it = s_item;
+        const unsigned long long it = s_item;
         if (it >= n_items) return;
-        uint64_t id = ovf_items[it];
-        uint64_t read = id / (uint64_t) P;
-        uint32_t iter = (uint32_t) (id % (uint64_t) P);
-        uint32_t len = lens[read];
-        uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;
-        uint32_t cnt = phase_count(jl, iter, (uint32_t) P);
-        const uint64_t *r = rec + (read * (uint64_t) P + iter) * cap_q;
+        const uint64_t id = items[it];
+        const uint64_t read = id / (uint64_t) P;
+        const uint32_t iter = (uint32_t) (id % (uint64_t) P);
+        const uint32_t len = lens[read];
+        const uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;
+        const uint32_t cnt = phase_count(jl, iter, (uint32_t) P);
+        const uint64_t *r = rec + id * cap_q;
 
-        unsigned long long my = 0;
-        for (uint32_t q = threadIdx.x; q < cnt; q += 256) my += r[q] >> 40;
-        atomicAdd(&s_hits, my);
+        uint32_t my = 0;
+        for (uint32_t q = tid; q < cnt; q += 256) my += (uint32_t) (r[q] >> 40);
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) my += __shfl_xor(my, m);
+        if (lane == 0) atomicAdd(&s_H, my);
         __syncthreads();
-        uint64_t hits = s_hits;
-        uint64_t cap = 1024;
-        while (cap < 2 * hits) cap <<= 1;
-        if (cap > table_cap) {
-            if (threadIdx.x == 0) {
-                atomicOr(&counters->error_flags, 1ull);
-                LrmPhaseRes z = {0, 0, 0, 0, 0, 0};
-                phase_res[id] = z;
-            }
+        const uint32_t H = s_H;
+        if (!multipass && H > limit) {
+            if (tid == 0) next_items[atomicAdd(next_n, 1ull)] = id;
             __syncthreads();
             continue;
         }
-        for (uint64_t s = threadIdx.x; s < cap; s += 256) {
-            tab[s].bucket = EMPTY64; tab[s].minkey = EMPTY64; tab[s].seq = EMPTY64; tab[s].count = 0;
-        }
-        __threadfence();
-        __syncthreads();
-        for (uint32_t q = threadIdx.x; q < cnt; q += 256) {
-            uint64_t e = r[q];
-            uint32_t rr = (uint32_t) (e >> 40);
-            uint64_t k = e & ((1ull << 40) - 1ull);
-            uint64_t jq = (uint64_t) iter + (uint64_t) q * (uint64_t) P;
-            for (uint32_t t = 0; t < rr; ++t) {
-                uint64_t key = ix.sa[k + t] - jq;
-                uint64_t bucket = key >> 4;
-                uint64_t seq = ((uint64_t) q << 32) | t;
-                uint64_t slot = ((bucket * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
-                while (true) {          // cap >= 2*hits: an empty slot always exists
-                    unsigned long long prev = atomicCAS(&tab[slot].bucket, EMPTY64, bucket);
-                    if (prev == EMPTY64 || prev == bucket) {
-                        atomicAdd(&tab[slot].count, 1u);
-                        atomicMin(&tab[slot].minkey, key);
-                        atomicMin(&tab[slot].seq, seq);
-                        break;
-                    }
-                    slot = (slot + 1) & (cap - 1);
-                }
+        const uint32_t passes = multipass ? (H + limit - 1) / limit : 1;
+
+        PhaseTop best = {};
+        for (uint32_t pass = 0; pass < passes; ++pass) {
+            for (uint32_t s = tid; s < slots; s += 256) {
+                t.bucket[s] = EMPTY64; t.count[s] = 0; t.first[s] = EMPTY32; t.minlow[s] = EMPTY32;
             }
-        }
-        __threadfence();
-        __syncthreads();
-        Cand b1 = {0u, 0u, EMPTY64}, b2 = {0u, 0u, EMPTY64};
-        for (uint64_t s = threadIdx.x; s < cap; s += 256) {
-            unsigned int c = __hip_atomic_load(&tab[s].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!c) continue;
-            unsigned long long sq = __hip_atomic_load(&tab[s].seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            Cand cd = {c, (uint32_t) s, sq};
-            if (better(cd, b1)) { b2 = b1; b1 = cd; }
-            else if (better(cd, b2)) b2 = cd;
-        }
-        s_c1[threadIdx.x] = b1;
-        s_c2[threadIdx.x] = b2;
-        __syncthreads();
-        for (int stride = 128; stride > 0; stride >>= 1) {
-            if ((int) threadIdx.x < stride) {
-                Cand a1 = s_c1[threadIdx.x], a2 = s_c2[threadIdx.x];
-                merge_top2(a1, a2, s_c1[threadIdx.x + stride], s_c2[threadIdx.x + stride]);
-                s_c1[threadIdx.x] = a1;
-                s_c2[threadIdx.x] = a2;
+            __syncthreads();
+            uint32_t hbase = 0;
+            for (uint32_t q0 = 0; q0 < cnt; q0 += 256) {
+                uint32_t q = q0 + tid;
+                uint64_t e = q < cnt ? r[q] : 0ull;
+                uint32_t rr = (uint32_t) (e >> 40);
+                uint32_t incl = rr;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    uint32_t v = __shfl_up(incl, d);
+                    if (lane >= d) incl += v;
+                }
+                if (lane == 63) s_wsum[wave] = incl;
+                __syncthreads();
+                uint32_t woff = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { uint32_t v = s_wsum[w]; if (w < wave) woff += v; total += v; }
+                s_incl[tid] = incl + woff;
+                s_k[tid] = e & ((1ull << 40) - 1ull);
+                __syncthreads();
+                for (uint32_t h = tid; h < total; h += 256) {
+                    int lo = 0, hi = 255;
+                    while (lo < hi) {
+                        int mid = (lo + hi) >> 1;
+                        if (s_incl[mid] > h) hi = mid; else lo = mid + 1;
+                    }
+                    uint32_t owner = (uint32_t) lo;
+                    uint32_t tt = h - (owner ? s_incl[owner - 1] : 0);
+                    uint64_t jq = (uint64_t) iter + (uint64_t) (q0 + owner) * (uint64_t) P;
+                    uint64_t key = ix.sa[s_k[owner] + tt] - jq;
+                    uint32_t hash = bucket_hash(key >> 4);
+                    // multi-pass: hash % passes picks the pass, the slot comes from the high hash bits
+                    if (passes == 1 || hash % passes == pass)
+                        if (!vote_insert(t, key, hbase + h, hash)) atomicOr(err_flags, 1ull);
+                }
+                hbase += total;
+                __syncthreads();
+            }
+            Cand b1 = {0u, EMPTY32, 0u}, b2 = {0u, EMPTY32, 0u};
+            for (uint32_t s = tid; s < slots; s += 256) {
+                Cand c = {t.count[s], t.first[s], s};
+                if (better(c, b1)) { b2 = b1; b1 = c; }
+                else if (better(c, b2)) b2 = c;
+            }
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                Cand o1 = shfl_xor_cand(b1, m), o2 = shfl_xor_cand(b2, m);
+                merge_top2(b1, b2, o1, o2);
+            }
+            if (lane == 0) { s_c1[wave] = b1; s_c2[wave] = b2; }
+            __syncthreads();
+            if (tid == 0) {
+                Cand a1 = s_c1[0], a2 = s_c2[0];
+                for (int w = 1; w < 4; ++w) merge_top2(a1, a2, s_c1[w], s_c2[w]);
+                // merge this pass's top-2 into the running top-2 (disjoint bucket sets)
+                Cand r1 = {best.val1, best.first1, 0u}, r2 = {best.val2, best.first2, 0u};
+                PhaseTop nb = best;
+                Cand cs[2] = {a1, a2};
+                for (int x = 0; x < 2; ++x) {
+                    const Cand &c = cs[x];
+                    if (!c.val) continue;
+                    uint64_t bk = t.bucket[c.slot], ky = (bk << 4) | t.minlow[c.slot];
+                    if (better(c, r1)) {
+                        nb.key2 = nb.key1; nb.bucket2 = nb.bucket1; nb.val2 = nb.val1; nb.first2 = nb.first1; r2 = r1;
+                        nb.key1 = ky; nb.bucket1 = bk; nb.val1 = c.val; nb.first1 = c.first; r1 = c;
+                    } else if (better(c, r2)) {
+                        nb.key2 = ky; nb.bucket2 = bk; nb.val2 = c.val; nb.first2 = c.first; r2 = c;
+                    }
+                }
+                best = nb;
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) {
-            Cand t1 = s_c1[0], t2 = s_c2[0];
-            LrmPhaseRes res = {0, 0, 0, 0, 0, 0};
-            if (t1.val) {
-                res.key1 = __hip_atomic_load(&tab[t1.slot].minkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                res.val1 = t1.val;
-                res.bucket1 = __hip_atomic_load(&tab[t1.slot].bucket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (t2.val) {
-                res.key2 = __hip_atomic_load(&tab[t2.slot].minkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                res.val2 = t2.val;
-                res.bucket2 = __hip_atomic_load(&tab[t2.slot].bucket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            phase_res[id] = res;
-        }
+        if (tid == 0) write_phase(&phase_res[id], best);
         __syncthreads();
     }
 }
@@ -555,8 +610,10 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
         uint32_t cpr = (uint32_t) ((bpr + 255) / 256);
         uint64_t blocks = n * cpr;
         if (blocks > 0x7fffffffull) { lrm_set_error("pack2bit grid too large"); return -1; }
+        lrm_time_begin(ws, LRM_K_PACK2BIT, stream);
         hipLaunchKernelGGL(pack2bit_kernel, dim3((uint32_t) blocks), dim3(256), 0, stream, d_reads, stride,
                            d_lens, (uint8_t *) ws->d_reads2, bpr, cpr, n);
+        lrm_time_end(ws, stream);
     }
     for (int round = 0; round < 2; ++round) {
         int lo = round == 0 ? 0 : 1;
@@ -567,21 +624,39 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
         uint32_t bpr = (uint32_t) (((uint64_t) np * cap_q + 255) / 256);
         uint64_t blocks = n * bpr;
         if (blocks > 0x7fffffffull) { lrm_set_error("seed_search grid too large: split the batch"); return -1; }
+        lrm_time_begin(ws, LRM_K_SEED_SEARCH, stream);
         hipLaunchKernelGGL(seed_search_kernel, dim3((uint32_t) blocks), dim3(256), 0, stream, idx->view,
                            ws->d_reads2, wpr, d_lens, dec, n, (int) seed_len, thres, lo, hi, cap_q, bpr,
                            ws->d_rec);
-        uint64_t *ovf = ws->d_ovf_items + (round == 0 ? 0 : ws->n_max);
+        lrm_time_end(ws, stream);
+        // tiered vote: wave kernel over every item, then the two workgroup tiers over their lists
+        uint64_t *list2 = ws->d_ovf_items + (round == 0 ? 0 : ws->n_max);
+        uint64_t *list3 = ws->d_ovf_items2 + (round == 0 ? 0 : ws->n_max);
+        unsigned long long *n2 = &ws->d_counters->tier_n[round][0], *n3 = &ws->d_counters->tier_n[round][1];
+        unsigned long long *h2 = &ws->d_counters->tier_head[round][0], *h3 = &ws->d_counters->tier_head[round][1];
         uint64_t items = n * (uint64_t) np;
         uint64_t vblocks = (items + 3) / 4;
         if (vblocks > 0x7fffffffull) { lrm_set_error("vote grid too large: split the batch"); return -1; }
-        hipLaunchKernelGGL(vote_kernel, dim3((uint32_t) vblocks), dim3(256), 0, stream, idx->view, ws->d_rec,
-                           d_lens, dec, n, (int) seed_len, lo, hi, cap_q, ws->d_phase, ovf, ws->d_counters,
-                           round);
-        hipLaunchKernelGGL(vote_fallback_kernel, dim3((uint32_t) ws->ovf_slots), dim3(256), 0, stream,
-                           idx->view, ws->d_rec, d_lens, (int) seed_len, cap_q, ws->d_phase, ovf,
-                           ws->d_counters, (GEntry *) ws->d_ovf_tables, ws->ovf_cap, round);
+        lrm_time_begin(ws, LRM_K_VOTE, stream);
+        hipLaunchKernelGGL(vote_wave_kernel, dim3((uint32_t) vblocks), dim3(256), 0, stream, idx->view, ws->d_rec,
+                           d_lens, dec, n, (int) seed_len, lo, hi, cap_q, ws->d_phase, list2, n2);
+        lrm_time_end(ws, stream);
+        lrm_time_begin(ws, LRM_K_VOTE_FALLBACK, stream);
+        {
+            size_t sh2 = (size_t) T2_SLOTS * 20, sh3 = (size_t) T3_SLOTS * 20;
+            hipLaunchKernelGGL(vote_block_kernel, dim3(256 * 3), dim3(256), sh2, stream, idx->view, ws->d_rec, d_lens,
+                               (int) seed_len, cap_q, ws->d_phase, list2, n2, h2, (uint32_t) T2_SLOTS,
+                               (uint32_t) T2_LIMIT, 0, list3, n3, &ws->d_counters->error_flags);
+            hipLaunchKernelGGL(vote_block_kernel, dim3(256 * 2), dim3(256), sh3, stream, idx->view, ws->d_rec, d_lens,
+                               (int) seed_len, cap_q, ws->d_phase, list3, n3, h3, (uint32_t) T3_SLOTS,
+                               (uint32_t) T3_LIMIT, 1, (uint64_t *) nullptr, (unsigned long long *) nullptr,
+                               &ws->d_counters->error_flags);
+        }
+        lrm_time_end(ws, stream);
+        lrm_time_begin(ws, LRM_K_DECIDE, stream);
         hipLaunchKernelGGL(decide_kernel, dim3((uint32_t) ((n + 255) / 256)), dim3(256), 0, stream, ws->d_phase,
                            d_lens, n, (int) seed_len, round, ws->d_decided, d_best, ws->d_counters);
+        lrm_time_end(ws, stream);
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -116,8 +116,19 @@ class DeviceMapper:
     def stats(self):
         st = capi.Stats()
         check(lib.lrm_workspace_stats(self.ws, C.byref(st), self._stream()), "lrm_workspace_stats")
-        return dict(vote_overflow_items=int(st.vote_overflow_items),
+        return dict(vote_tier2_items=int(st.vote_tier2_items), vote_tier3_items=int(st.vote_tier3_items),
                     reads_decided_phase0=int(st.reads_decided_phase0), gact_tiles=int(st.gact_tiles))
+
+    def set_timing(self, enable=True):
+        check(lib.lrm_workspace_set_timing(self.ws, int(enable)), "lrm_workspace_set_timing")
+
+    def timing(self):
+        """-> {kernel name: (total ms, launches)} accumulated since set_timing / the last call."""
+        ms = np.zeros(8, dtype=np.float64)
+        launches = np.zeros(8, dtype=np.uint64)
+        check(lib.lrm_workspace_timing(self.ws, ms.ctypes.data, launches.ctypes.data, self._stream()),
+              "lrm_workspace_timing")
+        return {lib.lrm_kernel_name(i).decode(): (float(ms[i]), int(launches[i])) for i in range(8)}
 
     def results(self, n):
         """Copy the outputs of the last seed+extend to numpy (host)."""

@@ -526,7 +526,10 @@ int orc_gact(const char *q, int n, const char *d, int m, orc_gact_params gp,
             }
         }
         int a = 0, b = 0;
-        while (a < tq && b < tt && (last || (a < cap && b < cap))) {
+        /* the walk keeps at most T-O bases of either sequence; in the tile that holds the read's
+         * end it may run on to the edge, but never past anti-diagonal 2(T-O), so the pointers a
+         * walk can touch are bounded the same way in every tile                              */
+        while (a < tq && b < tt && (last ? (a + b < 2 * cap) : (a < cap && b < cap))) {
             uint8_t p = P[a * pitch + b];
             if (p == 0) {
                 int eq = q[i + a] == d[j + b];
