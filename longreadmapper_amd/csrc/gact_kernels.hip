@@ -120,12 +120,15 @@ __device__ __forceinline__ int dpp_from_upper(int v, int fill) {   // lane L <- 
 template <bool TRACK, bool FULLBAND>
 __device__ __forceinline__ int gact_cell(int r_diag, int r_ins, int r_del, uint32_t qc, uint32_t dc,
                                          bool is_exit, bool inband, uint32_t &acc) {
-    int cd = r_diag + (qc == dc ? 1 : -1);
+    const bool eq = qc == dc;
+    int cd = r_diag + (eq ? 1 : -1);
     int m1 = (r_ins >= r_del ? r_ins : r_del) - 1;
     int best = cd >= m1 ? cd : m1;
     if (TRACK) {
+        // 2-bit pointer: 0 DIAG/match, 3 DIAG/mismatch, 1 INS, 2 DEL -- the walk needs no sequence reads
         uint32_t p1 = r_ins >= r_del ? 1u : 2u;        // INS before DEL on ties
-        uint32_t p = cd >= m1 ? 0u : p1;               // DIAG wins ties
+        uint32_t pd = eq ? 0u : 3u;
+        uint32_t p = cd >= m1 ? pd : p1;               // DIAG wins ties
         acc = (acc << 2) | p;
     }
     best = is_exit ? 0 : best;
@@ -144,8 +147,11 @@ __global__ __launch_bounds__(256) void gact_kernel(const char *__restrict__ read
                                                    uint64_t store_stride, int32_t *__restrict__ n_ops_out,
                                                    int32_t *__restrict__ score_out, LrmDevCounters *counters) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint64_t read = (uint64_t) blockIdx.x * 4 + wave;
+    // everything derived from the wave id is wave-uniform: keep it in SGPRs so that loop control
+    // and the traceback walk run on the scalar unit
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const uint64_t read = (uint64_t) blockIdx.x * 4 + (uint64_t) wave;
     if (read >= n_reads) return;
     if (!meta_r[read]) {                       // fenced: no extension (reference would read garbage)
         if (lane == 0) { n_ops_out[read] = 0; score_out[read] = -1; }
@@ -158,8 +164,8 @@ __global__ __launch_bounds__(256) void gact_kernel(const char *__restrict__ read
     uint8_t *dbuf = qbuf + L.seq_bytes;
     uint8_t *opsbuf = base + (size_t) L.tb_words * 256 + 2 * L.seq_bytes;
 
-    const int n = (int) lens[read];
-    const int m = tlens ? (int) tlens[read] : n;                 // alnmain.c:443-445: tlen == qlen
+    const int n = __builtin_amdgcn_readfirstlane((int) lens[read]);
+    const int m = tlens ? __builtin_amdgcn_readfirstlane((int) tlens[read]) : n;   // alnmain.c:443-445: tlen == qlen
     const uint8_t *q = reinterpret_cast<const uint8_t *>(reads) + read * stride;
     const uint8_t *d = reinterpret_cast<const uint8_t *>(content) + meta[read].loc;
     uint8_t *ops_out = store + read * store_stride;
@@ -239,26 +245,38 @@ __global__ __launch_bounds__(256) void gact_kernel(const char *__restrict__ read
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        // traceback walk from the anchor (uniform across the wavefront)
+        // Traceback walk from the anchor.  All state is wave-uniform.  One traceback dword holds 16
+        // anti-diagonals of one band lane, and a DIAG move keeps the lane (s += 2), so a whole run
+        // of DIAG moves is decoded from one LDS read with bit tricks: the run length is a
+        // count-trailing-zeros over the "is a gap" bits, its mismatches a popcount, and its op bytes
+        // are written by as many lanes at once.  The gap that ends the run is taken in the same
+        // iteration.  ~1 iteration per indel or per 8 DIAG moves instead of 1 per alignment column.
         int a = 0, b = 0, cnt = 0;
-        while (a < tq && b < tt && (last ? (a + b < 2 * cap) : (a < cap && b < cap))) {
-            int sw = a + b, dd = b - a;
-            uint32_t word = tb[(sw >> 4) * 64 + ((dd + 64) >> 1)];
-            uint32_t p = (word >> (2 * (sw & 15))) & 3u;
-            p = __builtin_amdgcn_readfirstlane(p);
-            uint8_t op;
-            if (p == 0) {
-                bool eq = qbuf[a] == dbuf[b];
-                op = eq ? '=' : 'X';
-                score += eq ? 0 : 1;
-                a++; b++;
-            } else if (p == 1) {
-                op = 'I'; score++; a++;
-            } else {
-                op = 'D'; score++; b++;
-            }
-            if (lane == 0) opsbuf[cnt] = op;
-            cnt++;
+        const int lim2 = 2 * cap;
+        while (a < tq && b < tt && (last ? (a + b < lim2) : (a < cap && b < cap))) {
+            const int sw = a + b, dd = b - a, e0 = sw & 15;
+            const uint32_t word = __builtin_amdgcn_readfirstlane(tb[(sw >> 4) * 64 + ((dd + 64) >> 1)]);
+            const uint32_t par = (e0 & 1) ? 0x44444444u : 0x11111111u;      // entries of this walk's parity
+            const uint32_t from = 0xFFFFFFFFu << (2 * e0);
+            const uint32_t gm = (word ^ (word >> 1)) & par & from;            // entries holding INS (01) / DEL (10)
+            const int egap = gm ? (__builtin_ctz(gm) >> 1) : 16 + (e0 & 1);
+            const int r = (egap - e0) >> 1;                                   // DIAG moves before the gap / word end
+            int rmax = min(tq - a, tt - b);
+            rmax = last ? min(rmax, (lim2 - sw + 1) >> 1) : min(rmax, min(cap - a, cap - b));
+            const int rr = min(r, rmax);
+            const int eend = e0 + 2 * rr;
+            const uint32_t below = eend >= 16 ? 0xFFFFFFFFu : ((1u << (2 * eend)) - 1u);
+            const uint32_t mm = word & (word >> 1) & par & from & below;      // DIAG/mismatch entries (11) in the run
+            if (lane < rr) opsbuf[cnt + lane] = ((word >> (2 * (e0 + 2 * lane))) & 3u) ? 'X' : '=';
+            const int a2 = a + rr, b2 = b + rr;
+            const bool more = a2 < tq && b2 < tt && (last ? (a2 + b2 < lim2) : (a2 < cap && b2 < cap));
+            const bool do_gap = gm != 0u && rr == r && more;
+            const uint32_t gp = (word >> (2 * (egap & 15))) & 3u;             // 1 INS, 2 DEL when do_gap
+            if (do_gap && lane == 0) opsbuf[cnt + rr] = gp == 1u ? 'I' : 'D';
+            score += __builtin_popcount(mm) + (do_gap ? 1 : 0);
+            cnt += rr + (do_gap ? 1 : 0);
+            a = a2 + ((do_gap && gp == 1u) ? 1 : 0);
+            b = b2 + ((do_gap && gp == 2u) ? 1 : 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();

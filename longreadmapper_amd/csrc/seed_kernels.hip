@@ -437,10 +437,16 @@ __global__ __launch_bounds__(256) void vote_block_kernel(LrmIndexView ix, const 
             continue;
         }
         const uint32_t passes = multipass ? (H + limit - 1) / limit : 1;
+        // clear / scan only as much of the table as this item can fill (<= 75 % load)
+        {
+            uint32_t per_pass = passes > 1 ? limit : H;
+            uint32_t eff = per_pass + per_pass / 3 + 64;
+            t.slots = eff < slots ? eff : slots;
+        }
 
         PhaseTop best = {};
         for (uint32_t pass = 0; pass < passes; ++pass) {
-            for (uint32_t s = tid; s < slots; s += 256) {
+            for (uint32_t s = tid; s < t.slots; s += 256) {
                 t.bucket[s] = EMPTY64; t.count[s] = 0; t.first[s] = EMPTY32; t.minlow[s] = EMPTY32;
             }
             __syncthreads();
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(256) void vote_block_kernel(LrmIndexView ix, const 
                 __syncthreads();
             }
             Cand b1 = {0u, EMPTY32, 0u}, b2 = {0u, EMPTY32, 0u};
-            for (uint32_t s = tid; s < slots; s += 256) {
+            for (uint32_t s = tid; s < t.slots; s += 256) {
                 Cand c = {t.count[s], t.first[s], s};
                 if (better(c, b1)) { b2 = b1; b1 = c; }
                 else if (better(c, b2)) b2 = c;
