@@ -16,6 +16,7 @@
 // 16 steps per dword and parked in LDS; the traceback walk reads them back.  Integer max/add
 // recurrences: nothing here is a contraction, MFMA does not apply.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "lrm_internal.h"
 
 #define GACT_NEG (-(1 << 28))
@@ -301,14 +302,373 @@ __global__ __launch_bounds__(256) void gact_kernel(const char *__restrict__ read
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// GACT v2: TWO reads per wavefront, packed 16-bit.
+//
+// Every lane register holds the same lattice point of two independent reads (read A in bits 0-15,
+// read B in bits 16-31) and the recurrences run on v_pk_* instructions, so one instruction stream
+// advances two tiles.  To make that work without per-half compares/selects:
+//   * scores are kept as V = 2R + s + BIAS (s = a+b of the point).  All three candidates of a point
+//     share s, so every max / tie decision is unchanged, and the score terms become
+//     DIAG: V - 4*[mismatch]   GAP: V - 3   EXIT: s + BIAS   -- no compare needed: the mismatch
+//     flag is pk_min_u16(q ^ d, 1);
+//   * valid V are >= 1 and "no such neighbour" is 0, so the DPP wave shift runs with bound_ctrl
+//     (out-of-wave lanes read 0) and needs no fill register;
+//   * traceback decisions are two bit-planes per read, N = "not DIAG" and G = "DEL rather than INS"
+//     (sign bits of two packed subtractions), 16 steps per 16-bit half; match/mismatch is
+//     recovered during the walk from the staged sequences, a whole DIAG run per instruction.
+// ----------------------------------------------------------------------------------------
+#define G2_BIAS 2560
+#define G2_PAD 40            // guard positions on both sides of the staged sequences (>= 33)
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+    v2s x = __builtin_bit_cast(v2s, a), y = __builtin_bit_cast(v2s, b);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(x, y));
+}
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    v2u x = __builtin_bit_cast(v2u, a), y = __builtin_bit_cast(v2u, b);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(x, y));
+}
+__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b) {
+    v2u x = __builtin_bit_cast(v2u, a), y = __builtin_bit_cast(v2u, b);
+    return __builtin_bit_cast(uint32_t, (v2u) (x + y));
+}
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) {
+    v2u x = __builtin_bit_cast(v2u, a), y = __builtin_bit_cast(v2u, b);
+    return __builtin_bit_cast(uint32_t, (v2u) (x - y));
+}
+__device__ __forceinline__ uint32_t pk_mul16(uint32_t a, uint32_t b) {
+    v2u x = __builtin_bit_cast(v2u, a), y = __builtin_bit_cast(v2u, b);
+    return __builtin_bit_cast(uint32_t, (v2u) (x * y));
+}
+__device__ __forceinline__ uint32_t pk_lshr16(uint32_t a, int n) {
+    v2u x = __builtin_bit_cast(v2u, a);
+    return __builtin_bit_cast(uint32_t, (v2u) (x >> (unsigned short) n));
+}
+__device__ __forceinline__ uint32_t pk_ashr16(uint32_t a, int n) {
+    v2s x = __builtin_bit_cast(v2s, a);
+    return __builtin_bit_cast(uint32_t, (v2s) (x >> (short) n));
+}
+__device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t) lo & 0xffffu) | ((uint32_t) hi << 16); }
+
+// The three packed instructions LLVM will not form from C (it rewrites min(x,1)*4 into two
+// compares + selects + a byte permute): written out.  All inputs/outputs are plain VGPRs and the
+// results feed only non-DPP VALU instructions, so no manual wait states are needed.
+__device__ __forceinline__ uint32_t pk_mismatch(uint32_t x) {         // per half: x != 0 ? 1 : 0
+    uint32_t z;
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(z) : "v"(x));
+    return z;
+}
+__device__ __forceinline__ uint32_t pk_mad_m4(uint32_t z, uint32_t v) { // per half: v - 4*z
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, -4, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(z), "v"(v));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_shift_in(uint32_t acc, uint32_t bit) {  // per half: acc*2 + bit
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(acc), "v"(bit));
+    return r;
+}
+
+template <bool TRACK, bool EXIT, bool FULLBAND>
+__device__ __forceinline__ uint32_t gact2_cell(uint32_t v_diag, uint32_t v_ins, uint32_t v_del, uint32_t qc,
+                                               uint32_t dc, uint32_t e_pk, uint32_t s_pk, uint32_t sb_pk,
+                                               bool inband, uint32_t &accN, uint32_t &accG) {
+    const uint32_t cd = pk_mad_m4(pk_mismatch(qc ^ dc), v_diag);        // DIAG: -4 on a mismatch
+    const uint32_t m1 = pk_sub16(pk_max_i16(v_ins, v_del), 0x00030003u); // best gap: -3
+    uint32_t best = pk_max_i16(cd, m1);
+    if (TRACK) {
+        accN = pk_shift_in(accN, pk_lshr16(pk_sub16(cd, m1), 15));       // cd < m1: not DIAG
+        accG = pk_shift_in(accG, pk_lshr16(pk_sub16(v_ins, v_del), 15)); // ins < del: DEL
+    }
+    if (EXIT) {          // only anti-diagonals that touch the tile's far boundary pay for this
+        const uint32_t interior = pk_ashr16(pk_sub16(s_pk, e_pk), 15);  // 0xFFFF where s < e
+        best = (interior & best) | (~interior & sb_pk);                 // exit / outside: V = s + BIAS
+    }
+    if (!FULLBAND) best = inband ? best : 0u;
+    return best;
+}
+
+// ----------------------------------------------------------------------------------------
+// GACT v3 = v2 with the traceback bit-planes kept in REGISTERS.
+// With the planes in LDS a wavefront needs 16 KiB and only 2 wavefronts fit a SIMD, which leaves
+// the dependent chain of the sweep exposed.  The walk's anti-diagonal index only ever grows, and a
+// plane word is one VGPR per 16-step block, so: the sweep moves each finished block into a
+// statically named register (switch on the block number, one v_mov per plane), and the
+// wave-uniform walk fetches the word of the lane it needs with v_readlane from the register the
+// same switch names.  LDS then holds only the staged sequences (3.1 KiB per wavefront) and
+// occupancy is set by registers (~5 wavefronts = 10 reads per SIMD).  The walk looks two blocks
+// ahead, so a DIAG run only ends at an indel or after >= 16 moves.
+// ----------------------------------------------------------------------------------------
+// (block, next block) pairs; the planes are plain local variables tbnK / tbgK (K = 0..32) of the kernel --
+// not an array or struct: LLVM sinks the stores of a switch over a[K] / s.mK into one dynamically
+// addressed store, which sends the whole object to scratch; distinct allocas are left alone.
+#define G3_CASES(X) X(0,1) X(1,2) X(2,3) X(3,4) X(4,5) X(5,6) X(6,7) X(7,8) X(8,9) X(9,10) X(10,11) X(11,12) X(12,13) X(13,14) X(14,15) X(15,16) X(16,17) X(17,18) X(18,19) X(19,20) X(20,21) X(21,22) X(22,23) X(23,24) X(24,25) X(25,26) X(26,27) X(27,28) X(28,29) X(29,30) X(30,31) X(31,32)
+
+template <bool FULLBAND, int NB>
+__global__ __launch_bounds__(256) void gact3_kernel(const char *__restrict__ reads, uint64_t stride,
+                                                    const uint32_t *__restrict__ lens,
+                                                    const lrm_seq_meta *__restrict__ meta,
+                                                    const int32_t *__restrict__ meta_r,
+                                                    const char *__restrict__ content,
+                                                    const uint32_t *__restrict__ tlens, uint64_t n_reads,
+                                                    int T, int O, int W, uint8_t *__restrict__ store,
+                                                    uint64_t store_stride, int32_t *__restrict__ n_ops_out,
+                                                    int32_t *__restrict__ score_out, LrmDevCounters *counters,
+                                                    int dbg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const uint64_t r0 = ((uint64_t) blockIdx.x * 4 + (uint64_t) wave) * 2;
+    if (r0 >= n_reads) return;
+
+    int n[2], m[2], i[2] = {0, 0}, j[2] = {0, 0}, nops[2] = {0, 0}, score[2] = {0, 0};
+    const uint8_t *q[2], *d[2];
+    uint8_t *ops_out[2];
+    bool ok[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint64_t r = r0 + (uint64_t) h;
+        const uint64_t rs = r < n_reads ? r : r0;
+        ok[h] = r < n_reads && meta_r[rs] != 0;
+        n[h] = ok[h] ? __builtin_amdgcn_readfirstlane((int) lens[rs]) : 0;
+        m[h] = ok[h] ? (tlens ? __builtin_amdgcn_readfirstlane((int) tlens[rs]) : n[h]) : 0;
+        q[h] = reinterpret_cast<const uint8_t *>(reads) + rs * stride;
+        d[h] = reinterpret_cast<const uint8_t *>(content) + (ok[h] ? meta[rs].loc : 0);
+        ops_out[h] = store + rs * store_stride;
+        if (r < n_reads && !ok[h] && lane == 0) { n_ops_out[r] = 0; score_out[r] = -1; }   // fenced
+    }
+    if (!ok[0] && !ok[1]) return;
+
+    const uint32_t seq_words = (uint32_t) T + 2 * G2_PAD;
+    uint32_t *qbuf = reinterpret_cast<uint32_t *>(smem) + (size_t) wave * 2 * seq_words + G2_PAD;
+    uint32_t *dbuf = qbuf + seq_words;
+
+    const int hw = W / 2;
+    const int dE = 2 * lane - 64, dO = 2 * lane - 63;
+    const bool inE = dE >= -hw && dE < hw, inO = dO >= -hw && dO < hw;
+    const int cap = T - O, lim2 = 2 * cap;
+    const int nblk = ((lim2 - 1) >> 4) + 1;
+    const int s_hi = nblk * 16 - 1;
+    unsigned tiles = 0;
+#define X(K, K1) uint32_t tbn##K = 0, tbg##K = 0;
+    G3_CASES(X)
+#undef X
+    const uint32_t tbn32 = 0, tbg32 = 0;
+#define TB_PUT(k_, an_, ag_) do { switch (k_) {                                   \
+        G3_CASES(TB_PUT_CASE)                                                         \
+        default: break; } } while (0)
+#define TB_PUT_CASE(K, K1) case K: if (K < NB) { tbn##K = accN; tbg##K = accG; } break;
+#define TB_GET_CASE(K, K1) case K: if (K < NB) {                                  \
+            n0 = (uint32_t) __builtin_amdgcn_readlane((int) tbn##K, ln_);             \
+            g0 = (uint32_t) __builtin_amdgcn_readlane((int) tbg##K, ln_);             \
+            n1 = (K1 < NB) ? (uint32_t) __builtin_amdgcn_readlane((int) tbn##K1, ln_) : 0u; \
+            g1 = (K1 < NB) ? (uint32_t) __builtin_amdgcn_readlane((int) tbg##K1, ln_) : 0u; \
+        } break;
+
+    while ((i[0] < n[0] && j[0] < m[0]) || (i[1] < n[1] && j[1] < m[1])) {
+        int tq[2], tt[2];
+        bool act[2], last[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            act[h] = i[h] < n[h] && j[h] < m[h];
+            tq[h] = act[h] ? min(T, n[h] - i[h]) : 0;
+            tt[h] = act[h] ? min(T, m[h] - j[h]) : 0;
+            last[h] = i[h] + tq[h] == n[h];
+            tiles += act[h] ? 1u : 0u;
+        }
+        for (int x = lane; x < T; x += 64) {
+            uint32_t qa = x < tq[0] ? q[0][i[0] + x] : 0u, qb = x < tq[1] ? q[1][i[1] + x] : 0u;
+            uint32_t da = x < tt[0] ? d[0][j[0] + x] : 0u, db = x < tt[1] ? d[1][j[1] + x] : 0u;
+            qbuf[x] = qa | (qb << 16);
+            dbuf[x] = da | (db << 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        const uint32_t eE = pack16(min(2 * tq[0] + dE, 2 * tt[0] - dE), min(2 * tq[1] + dE, 2 * tt[1] - dE));
+        const uint32_t eO = pack16(min(2 * tq[0] + dO, 2 * tt[0] - dO), min(2 * tq[1] + dO, 2 * tt[1] - dO));
+        uint32_t r1 = 0, r2 = 0, accN = 0, accG = 0;
+        int s = max(tq[0] + tt[0], tq[1] + tt[1]);
+        if (dbg & 1) s = 1;
+        const uint32_t *qp, *dp;
+        uint32_t qc = 0, dc = 0, qn, dn;
+        if ((s & 1) == 0) {
+            qp = qbuf + (s / 2 + 32 - lane);
+            dp = dbuf + (s / 2 - 32 + lane) + 1;
+            qc = *qp;
+        } else {
+            qp = qbuf + ((s - 1) / 2 + 32 - lane) + 1;
+            dp = dbuf + ((s - 1) / 2 - 31 + lane);
+            dc = *dp;
+        }
+        qn = qp[-1];
+        dn = dp[-1];
+
+        // Below s_free every lane of every ACTIVE read is strictly inside its tile, so the exit test
+        // (3 VALU + 3 SALU per step) is only paid on the first ~64 anti-diagonals of a tile.
+        int s_free = 0x7fffffff;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (act[h]) s_free = min(s_free, 2 * min(tq[h], tt[h]) - 64);
+
+#define G2_SPK(S) ((uint32_t) (S) * 0x00010001u)
+#define G2_ODD(TRACK, EXIT, S) do {                                                              \
+            qc = qn; qp -= 1; qn = qp[-1];                                                           \
+            uint32_t del_ = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) r1, DPP_WAVE_SHL1, 0xf, 0xf, true); \
+            uint32_t r0_ = gact2_cell<TRACK, EXIT, FULLBAND>(r2, r1, del_, qc, dc, eO, G2_SPK(S),    \
+                                                             G2_SPK((S) + G2_BIAS), inO, accN, accG); \
+            r2 = r1; r1 = r0_;                                                                       \
+        } while (0)
+#define G2_EVEN(TRACK, EXIT, S) do {                                                             \
+            dc = dn; dp -= 1; dn = dp[-1];                                                           \
+            uint32_t ins_ = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) r1, DPP_WAVE_SHR1, 0xf, 0xf, true); \
+            uint32_t r0_ = gact2_cell<TRACK, EXIT, FULLBAND>(r2, ins_, r1, qc, dc, eE, G2_SPK(S),    \
+                                                             G2_SPK((S) + G2_BIAS), inE, accN, accG); \
+            r2 = r1; r1 = r0_;                                                                       \
+        } while (0)
+#define G2_FLUSH(S) do { if (((S) & 15) == 0) TB_PUT((S) >> 4, accN, accG); } while (0)
+        // generic segment: anti-diagonals s .. LIM+1 (any parity at either end)
+#define G2_SEG(LIM, TRACK, EXIT) do {                                                            \
+            const int lim_ = (LIM);                                                                  \
+            if (s > lim_ && (s & 1) == 0) { G2_EVEN(TRACK, EXIT, s); if (TRACK) G2_FLUSH(s); s--; }  \
+            for (; s - 1 > lim_; s -= 2) {                                                           \
+                G2_ODD(TRACK, EXIT, s); G2_EVEN(TRACK, EXIT, s - 1); if (TRACK) G2_FLUSH(s - 1);     \
+            }                                                                                        \
+            if (s > lim_) { G2_ODD(TRACK, EXIT, s); s--; }                                           \
+        } while (0)
+
+        // phase A (no walk can reach these anti-diagonals: scores only), with then without exit test
+        G2_SEG(max(s_hi, s_free - 1), false, true);
+        if (s > s_hi && (s & 1) == 0) { G2_EVEN(false, false, s); s--; }      // the unrolled loops start on an odd s
+        for (; s - 7 > s_hi; s -= 8) {
+            G2_ODD(false, false, s);     G2_EVEN(false, false, s - 1); G2_ODD(false, false, s - 2); G2_EVEN(false, false, s - 3);
+            G2_ODD(false, false, s - 4); G2_EVEN(false, false, s - 5); G2_ODD(false, false, s - 6); G2_EVEN(false, false, s - 7);
+        }
+        G2_SEG(s_hi, false, false);
+        // phase B (scores + traceback bit-planes): exit test only for small tiles; then down to a
+        // 16-step block boundary; then whole blocks -- 16 steps, one flush, no per-step bookkeeping
+        G2_SEG(max(-1, s_free - 1), true, true);
+        if (s >= 0 && (s & 1) == 0) { G2_EVEN(true, false, s); G2_FLUSH(s); s--; }
+        for (; s >= 1 && (s & 15) != 15; s -= 2) {
+            G2_ODD(true, false, s); G2_EVEN(true, false, s - 1); G2_FLUSH(s - 1);
+        }
+        for (; s >= 15; s -= 16) {
+            G2_ODD(true, false, s);      G2_EVEN(true, false, s - 1);  G2_ODD(true, false, s - 2);  G2_EVEN(true, false, s - 3);
+            G2_ODD(true, false, s - 4);  G2_EVEN(true, false, s - 5);  G2_ODD(true, false, s - 6);  G2_EVEN(true, false, s - 7);
+            G2_ODD(true, false, s - 8);  G2_EVEN(true, false, s - 9);  G2_ODD(true, false, s - 10); G2_EVEN(true, false, s - 11);
+            G2_ODD(true, false, s - 12); G2_EVEN(true, false, s - 13); G2_ODD(true, false, s - 14); G2_EVEN(true, false, s - 15);
+            TB_PUT(s >> 4, accN, accG);
+        }
+#undef G2_SEG
+#undef G2_FLUSH
+#undef G2_ODD
+#undef G2_EVEN
+#undef G2_SPK
+
+        // traceback walks (wave-uniform), a 32-step window of the lane's bit-planes per iteration
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!act[h]) continue;
+            const int sh = 16 * h;
+            int a = 0, b = 0, cnt = 0, sc = 0;
+            uint8_t *out = ops_out[h] + nops[h];
+            if (dbg & 2) {
+                a = b = min(min(tq[h], tt[h]), cap);
+                i[h] += a; j[h] += b;
+                continue;
+            }
+            while (a < tq[h] && b < tt[h] && (last[h] ? (a + b < lim2) : (a < cap && b < cap))) {
+                const int sw = a + b, dd = b - a, e0 = sw & 15;
+                uint32_t n0 = 0, g0 = 0, n1 = 0, g1 = 0;
+                {
+                    const int ln_ = (dd + 64) >> 1;
+                    switch (sw >> 4) {
+                        G3_CASES(TB_GET_CASE)
+                        default: break;
+                    }
+                }
+                const uint32_t wN = ((n0 >> sh) & 0xffffu) | (((n1 >> sh) & 0xffffu) << 16);   // steps e0 .. 31
+                const uint32_t wG = ((g0 >> sh) & 0xffffu) | (((g1 >> sh) & 0xffffu) << 16);
+                const uint32_t par = (e0 & 1) ? 0xAAAAAAAAu : 0x55555555u;
+                const uint32_t gm = wN & par & (0xffffffffu << e0);
+                const int egap = gm ? __builtin_ctz(gm) : 32 + (e0 & 1);
+                const int r = (egap - e0) >> 1;
+                int rmax = min(tq[h] - a, tt[h] - b);
+                rmax = last[h] ? min(rmax, (lim2 - sw + 1) >> 1) : min(rmax, min(cap - a, cap - b));
+                const int rr = min(r, rmax);
+                bool neq = false;
+                if (lane < rr) {
+                    neq = (((qbuf[a + lane] ^ dbuf[b + lane]) >> sh) & 0xffffu) != 0u;
+                    out[cnt + lane] = neq ? 'X' : '=';
+                }
+                const int mism = __builtin_popcountll(__ballot(neq));
+                const int a2 = a + rr, b2 = b + rr;
+                const bool more = a2 < tq[h] && b2 < tt[h] && (last[h] ? (a2 + b2 < lim2) : (a2 < cap && b2 < cap));
+                const bool do_gap = gm != 0u && rr == r && more;
+                const bool is_del = ((wG >> (egap & 31)) & 1u) != 0u;
+                if (do_gap && lane == 0) out[cnt + rr] = is_del ? 'D' : 'I';
+                sc += mism + (do_gap ? 1 : 0);
+                cnt += rr + (do_gap ? 1 : 0);
+                a = a2 + ((do_gap && !is_del) ? 1 : 0);
+                b = b2 + ((do_gap && is_del) ? 1 : 0);
+            }
+            nops[h] += cnt;
+            score[h] += sc;
+            i[h] += a;
+            j[h] += b;
+            if (a + b == 0) { n[h] = 0; score[h] = -1; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (!ok[h]) continue;
+        const uint64_t r = r0 + (uint64_t) h;
+        if (score[h] >= 0 && i[h] < n[h]) {
+            int rest = n[h] - i[h];
+            for (int x = lane; x < rest; x += 64) ops_out[h][nops[h] + x] = 'I';
+            nops[h] += rest;
+            score[h] += rest;
+        }
+        if (lane == 0) {
+            n_ops_out[r] = score[h] >= 0 ? nops[h] : 0;
+            score_out[r] = score[h];
+        }
+    }
+    if (lane == 0) atomicAdd(&counters->gact_tiles, (unsigned long long) tiles);
+}
+
 typedef void (*gact_fn_t)(const char *, uint64_t, const uint32_t *, const lrm_seq_meta *, const int32_t *,
                           const char *, const uint32_t *, uint64_t, int, int, int, uint8_t *, uint64_t, int32_t *,
                           int32_t *, LrmDevCounters *);
+typedef void (*gact2_fn_t)(const char *, uint64_t, const uint32_t *, const lrm_seq_meta *, const int32_t *,
+                           const char *, const uint32_t *, uint64_t, int, int, int, uint8_t *, uint64_t, int32_t *,
+                           int32_t *, LrmDevCounters *, int);
 
 static int gact_launch(lrm_gact_params gp, uint64_t n, hipStream_t stream, const char *reads, uint64_t stride,
                        const uint32_t *lens, const lrm_seq_meta *meta, const int32_t *meta_r, const char *content,
                        const uint32_t *tlens, uint8_t *store, uint64_t store_stride, int32_t *n_ops, int32_t *score,
                        LrmDevCounters *counters) {
+    static int impl = -1;
+    if (impl < 0) { const char *e = getenv("LRM_GACT_IMPL"); impl = e ? atoi(e) : 3; }
+    static int dbg3 = -1;
+    if (dbg3 < 0) { const char *e = getenv("LRM_GACT_DBG"); dbg3 = e ? atoi(e) : 0; }
+    const int nblk = ((2 * (gp.T - gp.O) - 1) >> 4) + 1;
+    if (impl == 3 && nblk <= 32) {
+        size_t shmem3 = (size_t) 4 * 2 * ((size_t) gp.T + 2 * G2_PAD) * 4;
+        gact2_fn_t fn3;
+        if (nblk <= 26) fn3 = gp.W >= 128 ? gact3_kernel<true, 26> : gact3_kernel<false, 26>;
+        else fn3 = gp.W >= 128 ? gact3_kernel<true, 32> : gact3_kernel<false, 32>;
+        uint64_t blocks3 = (n + 7) / 8;
+        hipLaunchKernelGGL(fn3, dim3((uint32_t) blocks3), dim3(256), shmem3, stream, reads, stride, lens, meta, meta_r,
+                           content, tlens, n, gp.T, gp.O, gp.W, store, store_stride, n_ops, score, counters, dbg3);
+        return 0;
+    }
     GactLds L = gact_lds_layout(gp.T, gp.O);
     size_t shmem = (size_t) L.wave_bytes * 4;
     gact_fn_t fn = gp.W >= 128 ? gact_kernel<true> : gact_kernel<false>;
