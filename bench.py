@@ -179,8 +179,9 @@ def main():
     for name, (ms, launches) in ktimes.items():
         if launches == 0:
             continue
-        key = name.replace("_kernel", "")
-        alg = per_base.get(key)
+        key = {"vote_wave": "vote", "vote_wave2": "vote", "vote_block": "vote"}.get(name.replace("_kernel", ""),
+                                                                                 name.replace("_kernel", ""))
+        alg = per_base.get(key) if not name.startswith("vote") else None
         per_launch_bytes = alg * bases * args.steps / launches if alg else None
         avg_ms = ms / launches
         kernels[name] = dict(ms_total=round(ms, 3), launches=launches, avg_ms=round(avg_ms, 4),

@@ -175,10 +175,11 @@ typedef struct lrm_stats {
 int lrm_workspace_stats(lrm_workspace *ws, lrm_stats *out, void *stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (bench bookkeeping).
- * Kernel order: pack2bit, seed_search, vote, vote_fallback, decide, locus_resolve, revcomp, gact.
+ * Kernel order: pack2bit, seed_search, vote_wave (tier 1), vote_wave2 (tier 2), decide, locus_resolve,
+ * revcomp, gact, vote_block (tier 3).
  * lrm_workspace_timing synchronises the stream, ADDS the elapsed milliseconds and launch counts
- * of everything recorded since the last call into ms[8] / launches[8], and resets the record. */
-#define LRM_N_KERNELS 8
+ * of everything recorded since the last call into ms[9] / launches[9], and resets the record. */
+#define LRM_N_KERNELS 9
 int lrm_workspace_set_timing(lrm_workspace *ws, int enable);
 int lrm_workspace_timing(lrm_workspace *ws, double *ms, uint64_t *launches, void *stream);
 const char *lrm_kernel_name(int kernel);

@@ -225,7 +225,7 @@ extern "C" void lrm_workspace_free(lrm_workspace *ws) {
     if (!ws) return;
     (void) hipSetDevice(ws->device);
     (void) hipFree(ws->d_reads2); (void) hipFree(ws->d_rec); (void) hipFree(ws->d_phase); (void) hipFree(ws->d_decided);
-    (void) hipFree(ws->d_ovf_items); (void) hipFree(ws->d_ovf_items2); (void) hipFree(ws->d_counters);
+    (void) hipFree(ws->d_hcount); (void) hipFree(ws->d_counters);
     for (int i = 0; i < LRM_MAX_TIMED; ++i) {
         if (ws->ev_start[i]) (void) hipEventDestroy((hipEvent_t) ws->ev_start[i]);
         if (ws->ev_stop[i]) (void) hipEventDestroy((hipEvent_t) ws->ev_stop[i]);
@@ -257,8 +257,7 @@ extern "C" int lrm_workspace_create(lrm_workspace **out, lrm_index *idx, uint64_
         {(void **) &ws->d_rec, n_max * (uint64_t) ws->P * ws->cap_q * 8},
         {(void **) &ws->d_phase, n_max * (uint64_t) ws->P * sizeof(LrmPhaseRes)},
         {(void **) &ws->d_decided, n_max},
-        {(void **) &ws->d_ovf_items, n_max * (uint64_t) ws->P * 8},
-        {(void **) &ws->d_ovf_items2, n_max * (uint64_t) ws->P * 8},
+        {(void **) &ws->d_hcount, n_max * (uint64_t) ws->P * 4},
         {(void **) &ws->d_counters, sizeof(LrmDevCounters)},
     };
     for (auto &a : allocs) {
@@ -315,8 +314,14 @@ extern "C" int lrm_workspace_stats(lrm_workspace *ws, lrm_stats *out, void *stre
     LrmDevCounters c;
     HIPCHK(hipMemcpyAsync(&c, ws->d_counters, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t) stream));
     HIPCHK(hipStreamSynchronize((hipStream_t) stream));
-    out->vote_tier2_items = c.tier_n[0][0] + c.tier_n[1][0];
-    out->vote_tier3_items = c.tier_n[0][1] + c.tier_n[1][1];
+    {   // tier occupancy from the per-(read,phase) hit counts of the last seed call (host-side count)
+        std::vector<uint32_t> hc((size_t) ws->n_last * ws->P);
+        if (!hc.empty()) HIPCHK(hipMemcpy(hc.data(), ws->d_hcount, hc.size() * 4, hipMemcpyDeviceToHost));
+        uint64_t t2 = 0, t3 = 0;
+        for (uint32_t h : hc) { t2 += (h > 192 && h <= 768); t3 += (h > 768); }
+        out->vote_tier2_items = t2;
+        out->vote_tier3_items = t3;
+    }
     out->reads_decided_phase0 = c.decided_phase0;
     out->gact_tiles = c.gact_tiles;
     if (c.error_flags & 1ull) { lrm_set_error("vote table overflow in the multi-pass tier: results of some phases are invalid"); return -2; }
@@ -366,9 +371,9 @@ extern "C" int lrm_workspace_timing(lrm_workspace *ws, double *ms, uint64_t *lau
 }
 
 extern "C" const char *lrm_kernel_name(int k) {
-    static const char *names[LRM_K_COUNT] = {"pack2bit_kernel", "seed_search_kernel", "vote_kernel",
-                                             "vote_fallback_kernel", "decide_kernel", "locus_resolve_kernel",
-                                             "revcomp_kernel", "gact_kernel"};
+    static const char *names[LRM_K_COUNT] = {"pack2bit_kernel", "seed_search_kernel", "vote_wave_kernel",
+                                             "vote_wave2_kernel", "decide_kernel", "locus_resolve_kernel",
+                                             "revcomp_kernel", "gact_kernel", "vote_block_kernel"};
     return k >= 0 && k < LRM_K_COUNT ? names[k] : "?";
 }
 

@@ -79,8 +79,7 @@ struct LrmPhaseRes {
 
 // Device counters block (one per workspace).
 struct LrmDevCounters {
-    unsigned long long tier_n[2][2];     // [launch round][tier 2 / tier 3]: items pushed to that tier
-    unsigned long long tier_head[2][2];  // work-queue heads of the workgroup-tier kernels
+    unsigned long long reserved[8];
     unsigned long long decided_phase0;
     unsigned long long gact_tiles;
     unsigned long long error_flags;
@@ -88,7 +87,7 @@ struct LrmDevCounters {
 };
 
 enum LrmKernelId { LRM_K_PACK2BIT = 0, LRM_K_SEED_SEARCH, LRM_K_VOTE, LRM_K_VOTE_FALLBACK, LRM_K_DECIDE,
-                   LRM_K_LOCUS, LRM_K_REVCOMP, LRM_K_GACT, LRM_K_COUNT };
+                   LRM_K_LOCUS, LRM_K_REVCOMP, LRM_K_GACT, LRM_K_VOTE_BLOCK, LRM_K_COUNT };
 #define LRM_MAX_TIMED 4096
 
 struct lrm_workspace {
@@ -100,6 +99,7 @@ struct lrm_workspace {
     int ev_kernel[LRM_MAX_TIMED];
     int device;
     uint64_t n_max;
+    uint64_t n_last;         // reads in the last seed call (for stats)
     uint32_t max_len, seed_len, thres;
     uint32_t P;              // seed_len + 1 phases
     uint32_t cap_q;          // seeds per phase capacity
@@ -110,8 +110,7 @@ struct lrm_workspace {
     uint64_t *d_rec;         // per-seed records: n_max * P * cap_q
     LrmPhaseRes *d_phase;    // n_max * P
     uint8_t *d_decided;      // n_max
-    uint64_t *d_ovf_items;   // tier-2 item list (read*P+iter): round 0 at [0,n_max), round 1 after
-    uint64_t *d_ovf_items2;  // tier-3 item list, same layout
+    uint32_t *d_hcount;      // hits per (read, phase): routes an item to its vote-table tier
     LrmDevCounters *d_counters;
 };
 

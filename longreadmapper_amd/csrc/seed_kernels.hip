@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void seed_search_debug_kernel(LrmIndexView ix,
 // The vote table always lives in LDS.  Items ((read, phase) pairs) are tiered by their hit count
 // H = sum of rr, an upper bound on the distinct buckets:
 //   tier 1  H <= 192          one wavefront per item, 256 slots, 4 items per workgroup
-//   tier 2  H <= T2_LIMIT     one 256-thread workgroup per item, 2048 slots
+//   tier 2  H <= 768          one wavefront per item, 1024 slots, persistent grid over a list
 //   tier 3  any H             one workgroup per item, 3072 slots, ceil(H/limit) passes: pass p only
 //                             admits buckets with hash % passes == p, the per-pass top-2 are merged
 //                             (buckets of different passes are disjoint, so the merge is exact)
@@ -203,10 +203,12 @@ __global__ __launch_bounds__(256) void seed_search_debug_kernel(LrmIndexView ix,
 // ----------------------------------------------------------------------------------------
 #define T1_SLOTS 256
 #define T1_LIMIT 192
-#define T2_SLOTS 2048
-#define T2_LIMIT 1536
-#define T3_SLOTS 3072
-#define T3_LIMIT 2304
+#define T2A_SLOTS 512        // tier 2a / 2b: per-wavefront tables
+#define T2A_LIMIT 384
+#define T2W_SLOTS 1024
+#define T2W_LIMIT 768
+#define T3_SLOTS 1280
+#define T3_LIMIT 960
 #define EMPTY32 0xFFFFFFFFu
 
 struct Cand { uint32_t val; uint32_t first; uint32_t slot; };
@@ -275,97 +277,151 @@ __device__ __forceinline__ void write_phase(LrmPhaseRes *out, const PhaseTop &p)
     *out = res;
 }
 
-// ---- tier 1: one wavefront per item ---------------------------------------------------------
-__global__ __launch_bounds__(256) void vote_wave_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
-                                                        const uint32_t *__restrict__ lens,
-                                                        const uint8_t *__restrict__ decided, uint64_t n,
-                                                        int seed_len, int phase_lo, int phase_hi, uint32_t cap_q,
-                                                        LrmPhaseRes *__restrict__ phase_res,
-                                                        uint64_t *__restrict__ next_items,
-                                                        unsigned long long *next_n) {
-    __shared__ uint64_t s_bucket[4][T1_SLOTS];
-    __shared__ uint32_t s_count[4][T1_SLOTS], s_first[4][T1_SLOTS], s_minlow[4][T1_SLOTS];
-    __shared__ uint32_t s_incl[4][64];
-    __shared__ uint64_t s_k[4][64];
+// ---- tiers 1 and 2: one wavefront per item ---------------------------------------------------
+// First-seen order key of a hit = (seed ordinal q << tbits) | SA offset t  (t < thres <= 2^tbits),
+// strictly monotone in the reference's (j asc, k asc) insertion order, so no prefix sums are needed.
+// Seeds with a handful of hits are voted by their own lane; a seed with many hits (a repeat) is
+// spread over all 64 lanes.
+#define VOTE_BATCH 8          // records per lane kept in registers: one memory latency per 512 seeds
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int P = seed_len + 1;
-    const int np = phase_hi - phase_lo + 1;
-    uint64_t item = (uint64_t) blockIdx.x * 4 + wave;
-    if (item >= n * (uint64_t) np) return;
-    uint64_t read = item / (uint64_t) np;
-    int iter = phase_lo + (int) (item % (uint64_t) np);
-    if (decided && decided[read]) return;
-
-    uint32_t len = lens[read];
-    uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;
-    uint32_t cnt = phase_count(jl, (uint32_t) iter, (uint32_t) P);
-    const uint64_t id = read * (uint64_t) P + (uint64_t) iter;
-    const uint64_t *r = rec + id * cap_q;
-
-    // hit count of the phase (upper bound on distinct buckets)
-    uint32_t my = 0;
-    for (uint32_t q = lane; q < cnt; q += 64) my += (uint32_t) (r[q] >> 40);
+// Loads the records of seeds [q0, q0 + 64*VOTE_BATCH) of one phase, all loads in flight at once.
+__device__ __forceinline__ void load_records(const uint64_t *__restrict__ r, uint32_t cnt, uint32_t q0, int lane,
+                                             uint64_t (&e)[VOTE_BATCH]) {
 #pragma unroll
-    for (int m = 1; m < 64; m <<= 1) my += __shfl_xor(my, m);
-    const uint32_t H = my;
-    if (H == 0) {
-        if (lane == 0) { LrmPhaseRes z = {0, 0, 0, 0, 0, 0}; phase_res[id] = z; }
-        return;
+    for (int u = 0; u < VOTE_BATCH; ++u) {
+        uint32_t q = q0 + (uint32_t) u * 64 + (uint32_t) lane;
+        e[u] = q < cnt ? r[q] : 0ull;
     }
-    if (H > T1_LIMIT) {
-        if (lane == 0) next_items[atomicAdd(next_n, 1ull)] = id;
-        return;
-    }
-    VoteTable t = {s_bucket[wave], s_count[wave], s_first[wave], s_minlow[wave], T1_SLOTS};
+}
+
+// Votes the hits of 64 seeds (one per lane; e = packed record, q = seed ordinal).  Seeds with a
+// handful of hits are voted by their own lane; a seed with many hits (a repeat) is spread over the
+// 64 lanes of the wavefront.  passes > 1: only buckets with hash % passes == pass are admitted.
+// The SA gathers are the long-latency part, so they are issued in batches before any vote is cast:
+// the <= 4 entries of a small seed together, and the first 64 entries of up to 4 repeat seeds together.
+__device__ __forceinline__ bool vote_admit(const VoteTable &t, uint64_t key, uint32_t order, uint32_t passes,
+                                           uint32_t pass) {
+    uint32_t hash = bucket_hash(key >> 4);
+    if (passes == 1 || hash % passes == pass) return vote_insert(t, key, order, hash);
+    return true;
+}
+
+// Repeat seeds (rr > 4): the hits of one seed are a contiguous run of SA rows, read by the whole
+// wavefront at once; the first 64 rows of up to four such seeds are in flight together.
+struct BigList { uint64_t *k; uint32_t *q; uint32_t *incl; };     // (reserved) per-wavefront scratch
+#define BIG_CAP 64
+
+__device__ __forceinline__ bool vote_big_seeds(const LrmIndexView &ix, const VoteTable &t, uint32_t rr, uint64_t k,
+                                               uint32_t q0, uint32_t iter, uint32_t P, uint32_t tbits, int lane,
+                                               uint32_t passes, uint32_t pass) {
+    bool ok = true;
+    unsigned long long big = __ballot(rr > 4);
+    while (big) {
+        uint32_t rs[4], qs[4];
+        uint64_t ks[4], js[4], v[4];
 #pragma unroll
-    for (int x = 0; x < T1_SLOTS / 64; ++x) {
-        int s = lane + 64 * x;
+        for (int g = 0; g < 4; ++g) {
+            rs[g] = 0; qs[g] = 0; ks[g] = 0; js[g] = 0;
+            if (big) {
+                const int src = __builtin_ctzll(big);
+                big &= big - 1;
+                rs[g] = (uint32_t) __builtin_amdgcn_readlane((int) rr, src);
+                const uint32_t klo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) k, src);
+                const uint32_t khi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (k >> 32), src);
+                ks[g] = ((uint64_t) khi << 32) | klo;
+                qs[g] = q0 + (uint32_t) src;
+                js[g] = (uint64_t) iter + (uint64_t) qs[g] * (uint64_t) P;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = (uint32_t) lane < rs[g] ? ix.sa[ks[g] + (uint32_t) lane] : 0ull;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if ((uint32_t) lane < rs[g]) ok &= vote_admit(t, v[g] - js[g], (qs[g] << tbits) | (uint32_t) lane, passes, pass);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            for (uint32_t tt = (uint32_t) lane + 64; tt < rs[g]; tt += 64)
+                ok &= vote_admit(t, ix.sa[ks[g] + tt] - js[g], (qs[g] << tbits) | tt, passes, pass);
+    }
+    return ok;
+}
+
+__device__ __forceinline__ void load_small_hits(const LrmIndexView &ix, uint32_t rr, uint64_t k, uint64_t (&sv)[4]) {
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) sv[tt] = (rr <= 4 && (uint32_t) tt < rr) ? ix.sa[k + (uint32_t) tt] : 0ull;
+}
+
+__device__ __forceinline__ bool vote_small_hits(const VoteTable &t, uint32_t rr, const uint64_t (&sv)[4], uint32_t q,
+                                                uint64_t jq, uint32_t tbits, uint32_t passes, uint32_t pass) {
+    bool ok = true;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+        if (rr <= 4 && (uint32_t) tt < rr) ok &= vote_admit(t, sv[tt] - jq, (q << tbits) | (uint32_t) tt, passes, pass);
+    return ok;
+}
+
+__device__ __forceinline__ bool vote_chunk(const LrmIndexView &ix, const VoteTable &t, const BigList &bl, uint64_t e,
+                                           uint32_t q, uint32_t iter, uint32_t P, uint32_t tbits, int lane,
+                                           uint32_t passes, uint32_t pass) {
+    const uint32_t rr = (uint32_t) (e >> 40);
+    const uint64_t k = e & ((1ull << 40) - 1ull);
+    const uint64_t jq = (uint64_t) iter + (uint64_t) q * (uint64_t) P;      // alnmain.c:363-365 (u64 wrap kept)
+    uint64_t sv[4];
+    load_small_hits(ix, rr, k, sv);
+    bool ok = vote_small_hits(t, rr, sv, q, jq, tbits, passes, pass);
+    ok &= vote_big_seeds(ix, t, rr, k, q - (uint32_t) lane, iter, P, tbits, lane, passes, pass);
+    return ok;
+}
+
+template <int SLOTS>
+__device__ __forceinline__ void vote_item_wave(const LrmIndexView &ix, const uint64_t *__restrict__ r, uint32_t cnt,
+                                               uint32_t iter, uint32_t P, uint32_t H, uint32_t tbits, int lane,
+                                               uint64_t *tb_bucket, uint32_t *tb_count, uint32_t *tb_first,
+                                               uint32_t *tb_minlow, const BigList &bl, LrmPhaseRes *out,
+                                               uint64_t (&e0)[VOTE_BATCH]) {
+    VoteTable t = {tb_bucket, tb_count, tb_first, tb_minlow, 0};
+    {   // clear / scan only as much of the table as this item can fill (<= 75 % load)
+        uint32_t eff = H + H / 3 + 64;
+        t.slots = eff < (uint32_t) SLOTS ? eff : (uint32_t) SLOTS;
+    }
+    for (uint32_t s = lane; s < t.slots; s += 64) {
         t.bucket[s] = EMPTY64; t.count[s] = 0; t.first[s] = EMPTY32; t.minlow[s] = EMPTY32;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    uint32_t hbase = 0;
-    for (uint32_t q0 = 0; q0 < cnt; q0 += 64) {
-        uint32_t q = q0 + lane;
-        uint64_t e = q < cnt ? r[q] : 0ull;
-        uint32_t rr = (uint32_t) (e >> 40);
-        uint32_t incl = rr;
+    for (uint32_t qb = 0; qb < cnt; qb += 64 * VOTE_BATCH) {
+        uint64_t ev[VOTE_BATCH];
+        if (qb == 0) {
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t v = __shfl_up(incl, d);
-            if (lane >= d) incl += v;
+            for (int u = 0; u < VOTE_BATCH; ++u) ev[u] = e0[u];        // already loaded by the hit count
+        } else {
+            load_records(r, cnt, qb, lane, ev);
         }
-        uint32_t total = __shfl(incl, 63);
-        if (total == 0) continue;
-        s_incl[wave][lane] = incl;
-        s_k[wave][lane] = e & ((1ull << 40) - 1ull);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t h = lane; h < total; h += 64) {
-            int lo = 0, hi = 63;                 // owner = first lane whose inclusive sum exceeds h
-            while (lo < hi) {
-                int mid = (lo + hi) >> 1;
-                if (s_incl[wave][mid] > h) hi = mid; else lo = mid + 1;
-            }
-            uint32_t owner = (uint32_t) lo;
-            uint32_t tt = h - (owner ? s_incl[wave][owner - 1] : 0);
-            uint64_t jq = (uint64_t) iter + (uint64_t) (q0 + owner) * (uint64_t) P;
-            uint64_t key = ix.sa[s_k[wave][owner] + tt] - jq;          // alnmain.c:363-365 (u64 wrap kept)
-            vote_insert(t, key, hbase + h, bucket_hash(key >> 4));
+        uint64_t sv[VOTE_BATCH][4];
+#pragma unroll
+        for (int u = 0; u < VOTE_BATCH; ++u)                 // every small seed's SA entries: one memory latency
+            load_small_hits(ix, (uint32_t) (ev[u] >> 40), ev[u] & ((1ull << 40) - 1ull), sv[u]);
+#pragma unroll
+        for (int u = 0; u < VOTE_BATCH; ++u) {
+            const uint32_t q = qb + (uint32_t) u * 64 + (uint32_t) lane;
+            vote_small_hits(t, (uint32_t) (ev[u] >> 40), sv[u], q, (uint64_t) iter + (uint64_t) q * (uint64_t) P, tbits,
+                            1u, 0u);
         }
-        hbase += total;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < VOTE_BATCH; ++u) {
+            const uint32_t q0 = qb + (uint32_t) u * 64;
+            if (q0 >= cnt) break;
+            vote_big_seeds(ix, t, (uint32_t) (ev[u] >> 40), ev[u] & ((1ull << 40) - 1ull), q0, iter, P, tbits, lane,
+                           1u, 0u);
+        }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
     Cand b1 = {0u, EMPTY32, 0u}, b2 = {0u, EMPTY32, 0u};
-#pragma unroll
-    for (int x = 0; x < T1_SLOTS / 64; ++x) {
-        int s = lane + 64 * x;
-        Cand c = {t.count[s], t.first[s], (uint32_t) s};
+    for (uint32_t s = lane; s < t.slots; s += 64) {
+        Cand c = {t.count[s], t.first[s], s};
         if (better(c, b1)) { b2 = b1; b1 = c; }
         else if (better(c, b2)) b2 = c;
     }
@@ -378,27 +434,111 @@ __global__ __launch_bounds__(256) void vote_wave_kernel(LrmIndexView ix, const u
         PhaseTop p = {};
         if (b1.val) { p.val1 = b1.val; p.bucket1 = t.bucket[b1.slot]; p.key1 = (p.bucket1 << 4) | t.minlow[b1.slot]; }
         if (b2.val) { p.val2 = b2.val; p.bucket2 = t.bucket[b2.slot]; p.key2 = (p.bucket2 << 4) | t.minlow[b2.slot]; }
-        write_phase(&phase_res[id], p);
+        write_phase(out, p);
     }
 }
 
-// ---- tiers 2 and 3: one 256-thread workgroup per item, persistent grid over an item list -----
+// hit count of a phase = upper bound on its distinct buckets; the first 512 records stay in e0
+__device__ __forceinline__ uint32_t wave_hit_count(const uint64_t *__restrict__ r, uint32_t cnt, int lane,
+                                                   uint64_t (&e0)[VOTE_BATCH]) {
+    load_records(r, cnt, 0, lane, e0);
+    uint32_t my = 0;
+#pragma unroll
+    for (int u = 0; u < VOTE_BATCH; ++u) my += (uint32_t) (e0[u] >> 40);
+    for (uint32_t q = 64 * VOTE_BATCH + lane; q < cnt; q += 64) my += (uint32_t) (r[q] >> 40);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) my += __shfl_xor(my, m);
+    return my;
+}
+
+// tier 1: grid over every (read, phase) item, 256 slots per wavefront
+__global__ __launch_bounds__(256) void vote_wave_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
+                                                        const uint32_t *__restrict__ lens,
+                                                        const uint8_t *__restrict__ decided, uint64_t n,
+                                                        int seed_len, int phase_lo, int phase_hi, uint32_t cap_q,
+                                                        uint32_t tbits, uint32_t limit,
+                                                        LrmPhaseRes *__restrict__ phase_res,
+                                                        uint32_t *__restrict__ hcount) {
+    __shared__ uint64_t s_bucket[4][T1_SLOTS];
+    __shared__ uint32_t s_count[4][T1_SLOTS], s_first[4][T1_SLOTS], s_minlow[4][T1_SLOTS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int P = seed_len + 1;
+    const int np = phase_hi - phase_lo + 1;
+    uint64_t item = (uint64_t) blockIdx.x * 4 + wave;
+    if (item >= n * (uint64_t) np) return;
+    uint64_t read = item / (uint64_t) np;
+    int iter = phase_lo + (int) (item % (uint64_t) np);
+    if (decided && decided[read]) return;
+    uint32_t len = lens[read];
+    uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;
+    uint32_t cnt = phase_count(jl, (uint32_t) iter, (uint32_t) P);
+    const uint64_t id = read * (uint64_t) P + (uint64_t) iter;
+    const uint64_t *r = rec + id * cap_q;
+    uint64_t e0[VOTE_BATCH];
+    const uint32_t H = wave_hit_count(r, cnt, lane, e0);
+    // The hit count routes the item: no work lists, no global atomics (a single list-append counter
+    // saturates at ~90 appends/us, which made the appends cost more than the votes).  The larger
+    // tiers are launched over all items and drop the ones that are not theirs after one 4-byte read.
+    if (lane == 0) hcount[id] = H;
+    if (H == 0) {
+        if (lane == 0) { LrmPhaseRes z = {0, 0, 0, 0, 0, 0}; phase_res[id] = z; }
+        return;
+    }
+    if (H > limit) return;
+    const BigList bl = {nullptr, nullptr, nullptr};
+    vote_item_wave<T1_SLOTS>(ix, r, cnt, (uint32_t) iter, (uint32_t) P, H, tbits, lane, s_bucket[wave], s_count[wave],
+                             s_first[wave], s_minlow[wave], bl, &phase_res[id], e0);
+}
+
+// tier 2: grid over every item as well, ONE wavefront per workgroup (a wavefront that finds its
+// item in another tier exits and gives its LDS back at once); keeps lim_lo < H <= lim_hi.
+// Two instances: 512 slots (H <= 384) and 1024 slots (H <= 768).
+template <int SLOTS>
+__global__ __launch_bounds__(64) void vote_wave2_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
+                                                        const uint32_t *__restrict__ lens,
+                                                        const uint8_t *__restrict__ decided, uint64_t n,
+                                                        int seed_len, int phase_lo, int phase_hi, uint32_t cap_q,
+                                                        uint32_t tbits, uint32_t lim_lo, uint32_t lim_hi,
+                                                        LrmPhaseRes *__restrict__ phase_res,
+                                                        const uint32_t *__restrict__ hcount) {
+    __shared__ uint64_t tb_bucket[SLOTS];
+    __shared__ uint32_t tb_count[SLOTS], tb_first[SLOTS], tb_minlow[SLOTS];
+    const int lane = threadIdx.x & 63;
+    const int P = seed_len + 1;
+    const int np = phase_hi - phase_lo + 1;
+    const uint64_t item = (uint64_t) blockIdx.x;
+    if (item >= n * (uint64_t) np) return;
+    const uint64_t read = item / (uint64_t) np;
+    const int iter = phase_lo + (int) (item % (uint64_t) np);
+    if (decided && decided[read]) return;
+    const uint64_t id = read * (uint64_t) P + (uint64_t) iter;
+    const uint32_t H = hcount[id];
+    if (H <= lim_lo || H > lim_hi) return;
+    const uint32_t len = lens[read];
+    const uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;
+    const uint32_t cnt = phase_count(jl, (uint32_t) iter, (uint32_t) P);
+    const uint64_t *r = rec + id * cap_q;
+    uint64_t e0[VOTE_BATCH];
+    load_records(r, cnt, 0, lane, e0);
+    const BigList bl = {nullptr, nullptr, nullptr};
+    vote_item_wave<SLOTS>(ix, r, cnt, (uint32_t) iter, (uint32_t) P, H, tbits, lane, tb_bucket, tb_count, tb_first,
+                          tb_minlow, bl, &phase_res[id], e0);
+}
+
+// ---- tier 3: one 256-thread workgroup per item; a workgroup owns T3_GROUP consecutive items and
+// works on those whose hit count exceeds the wavefront tiers.  The table is shared by the workgroup
+// and an item takes ceil(H / limit) passes over its hits.  Needs the 32-bit (q,t) order key.
+#define T3_GROUP 16
 __global__ __launch_bounds__(256) void vote_block_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
-                                                         const uint32_t *__restrict__ lens, int seed_len,
-                                                         uint32_t cap_q, LrmPhaseRes *__restrict__ phase_res,
-                                                         const uint64_t *__restrict__ items,
-                                                         const unsigned long long *n_items_p,
-                                                         unsigned long long *head, uint32_t slots, uint32_t limit,
-                                                         int multipass, uint64_t *__restrict__ next_items,
-                                                         unsigned long long *next_n,
+                                                         const uint32_t *__restrict__ lens,
+                                                         const uint8_t *__restrict__ decided, uint64_t n,
+                                                         int seed_len, int phase_lo, int phase_hi, uint32_t cap_q,
+                                                         LrmPhaseRes *__restrict__ phase_res,
+                                                         const uint32_t *__restrict__ hcount, uint32_t slots,
+                                                         uint32_t limit, uint32_t lim_lo, uint32_t tbits,
                                                          unsigned long long *err_flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t vsmem[];
-    __shared__ unsigned long long s_item;
-    __shared__ uint32_t s_incl[256];
-    __shared__ uint64_t s_k[256];
-    __shared__ uint32_t s_wsum[4];
     __shared__ Cand s_c1[4], s_c2[4];
-    __shared__ uint32_t s_H;
 
     VoteTable t;
     t.slots = slots;
@@ -409,84 +549,43 @@ __global__ __launch_bounds__(256) void vote_block_kernel(LrmIndexView ix, const 
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int P = seed_len + 1;
-    const unsigned long long n_items = *n_items_p;
+    const int np = phase_hi - phase_lo + 1;
+    const uint64_t n_items = n * (uint64_t) np;
 
-    while (true) {
-        if (tid == 0) { s_item = atomicAdd(head, 1ull); s_H = 0; }
-        __syncthreads();
-        const unsigned long long it = s_item;
-        if (it >= n_items) return;
-        const uint64_t id = items[it];
-        const uint64_t read = id / (uint64_t) P;
-        const uint32_t iter = (uint32_t) (id % (uint64_t) P);
+    for (int g = 0; g < T3_GROUP; ++g) {
+        const uint64_t item = (uint64_t) blockIdx.x * T3_GROUP + g;
+        if (item >= n_items) return;
+        const uint64_t read = item / (uint64_t) np;
+        const uint32_t iter = (uint32_t) phase_lo + (uint32_t) (item % (uint64_t) np);
+        if (decided && decided[read]) continue;
+        const uint64_t id = read * (uint64_t) P + (uint64_t) iter;
+        const uint32_t H = hcount[id];
+        if (H <= lim_lo) continue;
         const uint32_t len = lens[read];
         const uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;
         const uint32_t cnt = phase_count(jl, iter, (uint32_t) P);
         const uint64_t *r = rec + id * cap_q;
-
-        uint32_t my = 0;
-        for (uint32_t q = tid; q < cnt; q += 256) my += (uint32_t) (r[q] >> 40);
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) my += __shfl_xor(my, m);
-        if (lane == 0) atomicAdd(&s_H, my);
-        __syncthreads();
-        const uint32_t H = s_H;
-        if (!multipass && H > limit) {
-            if (tid == 0) next_items[atomicAdd(next_n, 1ull)] = id;
-            __syncthreads();
-            continue;
-        }
-        const uint32_t passes = multipass ? (H + limit - 1) / limit : 1;
-        // clear / scan only as much of the table as this item can fill (<= 75 % load)
+        const uint32_t passes = (H + limit - 1) / limit;
         {
             uint32_t per_pass = passes > 1 ? limit : H;
             uint32_t eff = per_pass + per_pass / 3 + 64;
             t.slots = eff < slots ? eff : slots;
         }
-
         PhaseTop best = {};
         for (uint32_t pass = 0; pass < passes; ++pass) {
             for (uint32_t s = tid; s < t.slots; s += 256) {
                 t.bucket[s] = EMPTY64; t.count[s] = 0; t.first[s] = EMPTY32; t.minlow[s] = EMPTY32;
             }
             __syncthreads();
-            uint32_t hbase = 0;
-            for (uint32_t q0 = 0; q0 < cnt; q0 += 256) {
-                uint32_t q = q0 + tid;
-                uint64_t e = q < cnt ? r[q] : 0ull;
-                uint32_t rr = (uint32_t) (e >> 40);
-                uint32_t incl = rr;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    uint32_t v = __shfl_up(incl, d);
-                    if (lane >= d) incl += v;
-                }
-                if (lane == 63) s_wsum[wave] = incl;
-                __syncthreads();
-                uint32_t woff = 0, total = 0;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) { uint32_t v = s_wsum[w]; if (w < wave) woff += v; total += v; }
-                s_incl[tid] = incl + woff;
-                s_k[tid] = e & ((1ull << 40) - 1ull);
-                __syncthreads();
-                for (uint32_t h = tid; h < total; h += 256) {
-                    int lo = 0, hi = 255;
-                    while (lo < hi) {
-                        int mid = (lo + hi) >> 1;
-                        if (s_incl[mid] > h) hi = mid; else lo = mid + 1;
-                    }
-                    uint32_t owner = (uint32_t) lo;
-                    uint32_t tt = h - (owner ? s_incl[owner - 1] : 0);
-                    uint64_t jq = (uint64_t) iter + (uint64_t) (q0 + owner) * (uint64_t) P;
-                    uint64_t key = ix.sa[s_k[owner] + tt] - jq;
-                    uint32_t hash = bucket_hash(key >> 4);
-                    // multi-pass: hash % passes picks the pass, the slot comes from the high hash bits
-                    if (passes == 1 || hash % passes == pass)
-                        if (!vote_insert(t, key, hbase + h, hash)) atomicOr(err_flags, 1ull);
-                }
-                hbase += total;
-                __syncthreads();
+            bool ok = true;
+            for (uint32_t q0 = 0; q0 < cnt; q0 += 256) {      // each wavefront votes its own 64 seeds
+                const uint32_t qw = q0 + (uint32_t) wave * 64, q = qw + lane;
+                const uint64_t e = q < cnt ? r[q] : 0ull;
+                const BigList bl = {nullptr, nullptr, nullptr};
+                ok &= vote_chunk(ix, t, bl, e, q, iter, (uint32_t) P, tbits, lane, passes, pass);
             }
+            if (!ok) atomicOr(err_flags, 1ull);
+            __syncthreads();
             Cand b1 = {0u, EMPTY32, 0u}, b2 = {0u, EMPTY32, 0u};
             for (uint32_t s = tid; s < t.slots; s += 256) {
                 Cand c = {t.count[s], t.first[s], s};
@@ -611,6 +710,8 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
     (void) max_len; (void) thres;
 
     HIPCHK(hipMemsetAsync(ws->d_counters, 0, sizeof(LrmDevCounters), stream));
+    HIPCHK(hipMemsetAsync(ws->d_hcount, 0, n * (uint64_t) P * 4, stream));
+    ws->n_last = n;
     {
         uint64_t bpr = wpr * 8;
         uint32_t cpr = (uint32_t) ((bpr + 255) / 256);
@@ -635,27 +736,37 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
                            ws->d_reads2, wpr, d_lens, dec, n, (int) seed_len, thres, lo, hi, cap_q, bpr,
                            ws->d_rec);
         lrm_time_end(ws, stream);
-        // tiered vote: wave kernel over every item, then the two workgroup tiers over their lists
-        uint64_t *list2 = ws->d_ovf_items + (round == 0 ? 0 : ws->n_max);
-        uint64_t *list3 = ws->d_ovf_items2 + (round == 0 ? 0 : ws->n_max);
-        unsigned long long *n2 = &ws->d_counters->tier_n[round][0], *n3 = &ws->d_counters->tier_n[round][1];
-        unsigned long long *h2 = &ws->d_counters->tier_head[round][0], *h3 = &ws->d_counters->tier_head[round][1];
+        // tiered vote: every tier is launched over all items and keeps the ones in its hit-count range
         uint64_t items = n * (uint64_t) np;
         uint64_t vblocks = (items + 3) / 4;
         if (vblocks > 0x7fffffffull) { lrm_set_error("vote grid too large: split the batch"); return -1; }
+        uint32_t tbits = 1;
+        while ((1u << tbits) < thres && tbits < 31) tbits++;
+        if (((uint64_t) cap_q << tbits) > 0xffffffffull) {
+            lrm_set_error("read too long for the vote order key: cap_q %u << %u bits exceeds 32 bits", cap_q, tbits);
+            return -1;
+        }
         lrm_time_begin(ws, LRM_K_VOTE, stream);
         hipLaunchKernelGGL(vote_wave_kernel, dim3((uint32_t) vblocks), dim3(256), 0, stream, idx->view, ws->d_rec,
-                           d_lens, dec, n, (int) seed_len, lo, hi, cap_q, ws->d_phase, list2, n2);
+                           d_lens, dec, n, (int) seed_len, lo, hi, cap_q, tbits, (uint32_t) T1_LIMIT, ws->d_phase,
+                           ws->d_hcount);
         lrm_time_end(ws, stream);
         lrm_time_begin(ws, LRM_K_VOTE_FALLBACK, stream);
         {
-            size_t sh2 = (size_t) T2_SLOTS * 20, sh3 = (size_t) T3_SLOTS * 20;
-            hipLaunchKernelGGL(vote_block_kernel, dim3(256 * 3), dim3(256), sh2, stream, idx->view, ws->d_rec, d_lens,
-                               (int) seed_len, cap_q, ws->d_phase, list2, n2, h2, (uint32_t) T2_SLOTS,
-                               (uint32_t) T2_LIMIT, 0, list3, n3, &ws->d_counters->error_flags);
-            hipLaunchKernelGGL(vote_block_kernel, dim3(256 * 2), dim3(256), sh3, stream, idx->view, ws->d_rec, d_lens,
-                               (int) seed_len, cap_q, ws->d_phase, list3, n3, h3, (uint32_t) T3_SLOTS,
-                               (uint32_t) T3_LIMIT, 1, (uint64_t *) nullptr, (unsigned long long *) nullptr,
+            size_t sh3 = (size_t) T3_SLOTS * 20;
+            if (items > 0x7fffffffull) { lrm_set_error("vote grid too large: split the batch"); return -1; }
+            hipLaunchKernelGGL(vote_wave2_kernel<T2A_SLOTS>, dim3((uint32_t) items), dim3(64), 0, stream, idx->view,
+                               ws->d_rec, d_lens, dec, n, (int) seed_len, lo, hi, cap_q, tbits, (uint32_t) T1_LIMIT,
+                               (uint32_t) T2A_LIMIT, ws->d_phase, ws->d_hcount);
+            hipLaunchKernelGGL(vote_wave2_kernel<T2W_SLOTS>, dim3((uint32_t) items), dim3(64), 0, stream, idx->view,
+                               ws->d_rec, d_lens, dec, n, (int) seed_len, lo, hi, cap_q, tbits, (uint32_t) T2A_LIMIT,
+                               (uint32_t) T2W_LIMIT, ws->d_phase, ws->d_hcount);
+            lrm_time_end(ws, stream);
+            lrm_time_begin(ws, LRM_K_VOTE_BLOCK, stream);
+            uint64_t b3 = (items + T3_GROUP - 1) / T3_GROUP;
+            hipLaunchKernelGGL(vote_block_kernel, dim3((uint32_t) b3), dim3(256), sh3, stream, idx->view, ws->d_rec,
+                               d_lens, dec, n, (int) seed_len, lo, hi, cap_q, ws->d_phase, ws->d_hcount,
+                               (uint32_t) T3_SLOTS, (uint32_t) T3_LIMIT, (uint32_t) T2W_LIMIT, tbits,
                                &ws->d_counters->error_flags);
         }
         lrm_time_end(ws, stream);

@@ -124,11 +124,11 @@ class DeviceMapper:
 
     def timing(self):
         """-> {kernel name: (total ms, launches)} accumulated since set_timing / the last call."""
-        ms = np.zeros(8, dtype=np.float64)
-        launches = np.zeros(8, dtype=np.uint64)
+        ms = np.zeros(9, dtype=np.float64)
+        launches = np.zeros(9, dtype=np.uint64)
         check(lib.lrm_workspace_timing(self.ws, ms.ctypes.data, launches.ctypes.data, self._stream()),
               "lrm_workspace_timing")
-        return {lib.lrm_kernel_name(i).decode(): (float(ms[i]), int(launches[i])) for i in range(8)}
+        return {lib.lrm_kernel_name(i).decode(): (float(ms[i]), int(launches[i])) for i in range(9)}
 
     def results(self, n):
         """Copy the outputs of the last seed+extend to numpy (host)."""
