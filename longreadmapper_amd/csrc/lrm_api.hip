@@ -90,8 +90,8 @@ extern "C" int lrm_index_pack_blob(const lrm_dna_fmi *fmi, const lrm_lc_hash *lc
     const uint64_t ratio = (uint64_t) fmi->o_ratio;
     for (uint64_t i = 0; i < L; ++i) {
         if ((i & (LRM_OCC_ROWS - 1)) == 0) {
-            LrmOccBlock *b = &occ[i >> 7];
-            b->cnt[0] = run[0]; b->cnt[1] = run[1]; b->cnt[2] = run[2]; b->cnt[3] = run[3];
+            LrmOccBlock *b = &occ[i >> 6];
+            for (int c = 0; c < 4; ++c) b->sym[c].cnt = run[c];
         }
         if (fmi->o && ratio > 0 && i % ratio == 0) {
             const uint64_t *o = fmi->o + 4 * (i / ratio);
@@ -103,20 +103,17 @@ extern "C" int lrm_index_pack_blob(const lrm_dna_fmi *fmi, const lrm_lc_hash *lc
         char ch = fmi->bwt[i];
         int code = code_of(ch);
         if (code < 0) {
-            if (ch == '$' && dollar == ~0ull) { dollar = i; code = 0; }
+            if (ch == '$' && dollar == ~0ull) { dollar = i; }
             else { lrm_set_error("bwt row %llu holds byte 0x%02x (only upper-case ACGT and one '$' supported)", (unsigned long long) i, (unsigned) (unsigned char) ch); return -1; }
         } else {
             run[code]++;
-        }
-        occ[i >> 7].bits[(i & 127) >> 5] |= (uint64_t) code << (2 * (i & 31));
-    }
-    {   // spare block(s) after the last row carry the final counts
-        for (uint64_t b = (L + LRM_OCC_ROWS - 1) / LRM_OCC_ROWS; b < h.n_blocks; ++b) {
-            occ[b].cnt[0] = run[0]; occ[b].cnt[1] = run[1]; occ[b].cnt[2] = run[2]; occ[b].cnt[3] = run[3];
+            occ[i >> 6].sym[code].mask |= 1ull << (i & 63);
         }
     }
     if (dollar == ~0ull) { lrm_set_error("bwt has no '$' row"); return -1; }
     h.dollar_row = dollar;
+    for (uint64_t b = (L + LRM_OCC_ROWS - 1) / LRM_OCC_ROWS; b < h.n_blocks; ++b)     // spare block(s): final counts
+        for (int c = 0; c < 4; ++c) occ[b].sym[c].cnt = run[c];
 
     // lc table, permuted to the LSB-first code
     uint64_t *lc = (uint64_t *) (base + h.off_lc);

@@ -4,13 +4,13 @@
 // reference's in-memory arrays:
 //
 //   [BlobHeader 256 B]
-//   [occ blocks]   one 64-byte block per 128 BWT rows:
-//                    u64 cnt[4]   #A,#C,#G,#T in bwt[0 .. 128*blk)   ('$' not counted)
-//                    u64 bits[4]  the 128 rows, 2 bits each, row r at word r/32, bit 2*(r%32)
-//                  -> one rank query == ONE aligned 64-B gather (the reference layout,
-//                     fmidx.c:277-293, needs an 8-B o[] read plus a <=32-B bwt scan in a
-//                     different array).  The '$' row is stored as code 0 and compensated
-//                     through header.dollar_row.
+//   [occ blocks]   one 64-byte block per 64 BWT rows: for each symbol A,C,G,T a 16-byte pair
+//                    u64 cnt    # of the symbol in bwt[0 .. 64*blk)       ('$' not counted)
+//                    u64 mask   bit r set <=> bwt[64*blk + r] is the symbol
+//                  -> one rank query == ONE aligned 16-B gather + one 64-bit popcount (the
+//                     reference layout, fmidx.c:277-293, needs an 8-B o[] read plus a <=32-B
+//                     byte-compare scan of bwt[] in a different array).  The '$' row sets no
+//                     mask bit, so it needs no special case.
 //   [lc table]     4^hlen entries {u64 k, u64 l}, indexed by the LSB-first 2-bit code of the
 //                  hlen-mer (base i at bits 2i..2i+1) so the kernel extracts the index as one
 //                  bit field of the packed read.  (reference: first base most significant,
@@ -25,12 +25,15 @@
 #include "../../include/lrm_accel.h"
 
 #define LRM_BLOB_MAGIC 0x4c524d424c4f4231ull   // "LRMBLOB1"
-#define LRM_OCC_ROWS 128
+#define LRM_OCC_ROWS 64
 
-struct LrmOccBlock {
-    uint64_t cnt[4];
-    uint64_t bits[4];
+// One rank query = ONE 16-byte gather + one 64-bit popcount: per 64 BWT rows and per symbol a
+// {rank prefix, occurrence bitmask} pair; the four symbols of a block share a 64-byte line.
+struct LrmOccEntry {
+    uint64_t cnt;       // # of this symbol in bwt[0 .. 64*blk)
+    uint64_t mask;      // bit r set <=> bwt[64*blk + r] is this symbol ('$' sets no bit)
 };
+struct LrmOccBlock { LrmOccEntry sym[4]; };
 static_assert(sizeof(LrmOccBlock) == 64, "occ block must be one 64-B line");
 
 struct LrmMtaDev { uint64_t offset, seq_len; };

@@ -15,6 +15,7 @@
 // speculatively and replaying the decisions in order is exact.  To avoid 21x waste on
 // clean reads the host launches phase 0 first and phases 1..s only for undecided reads.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "lrm_internal.h"
 
 #define EMPTY64 0xFFFFFFFFFFFFFFFFull
@@ -47,56 +48,15 @@ __global__ __launch_bounds__(256) void pack2bit_kernel(const char *__restrict__ 
 }
 
 // ----------------------------------------------------------------------------------------
-// FM rank on the 64-byte occ blocks
+// FM rank: rank(c, loc) = # of c in bwt[0..loc] == _occ_access (fmidx.c:277-293).
+// One 16-byte gather {prefix, mask} and one popcount.  The kernel is bound by the number of
+// per-lane memory requests, not by bytes or ALU, so the layout is built to make a rank ONE request.
 // ----------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t match_count(uint64_t w, uint64_t pat, uint32_t nrows) {
-    // rows whose 2-bit symbol equals the pattern, among the first nrows (0..32) rows of w
-    uint64_t x = w ^ pat;
-    uint64_t m = ~(x | (x >> 1)) & 0x5555555555555555ull;
-    uint64_t mask = nrows >= 32 ? ~0ull : ((1ull << (2 * nrows)) - 1ull);
-    return (uint32_t) __popcll(m & mask);
-}
-
-__device__ __forceinline__ uint64_t block_rank(const LrmIndexView &ix, uint64_t blk, const uint64_t cnt_c,
-                                               const uint64_t b0, const uint64_t b1, const uint64_t b2,
-                                               const uint64_t b3, uint32_t c, uint32_t r) {
-    // # of symbol c in rows [128*blk, 128*blk + r]  (r inclusive, 0..127) + block prefix
-    uint64_t pat = (uint64_t) c * 0x5555555555555555ull;
-    uint32_t n = r + 1;
-    uint32_t cnt = match_count(b0, pat, n);
-    cnt += match_count(b1, pat, n > 32 ? n - 32 : 0);
-    cnt += match_count(b2, pat, n > 64 ? n - 64 : 0);
-    cnt += match_count(b3, pat, n > 96 ? n - 96 : 0);
-    uint64_t res = cnt_c + cnt;
-    // the '$' row is stored as code 0; the reference never counts it (fmidx.c:290 compares bytes)
-    if (c == 0 && (ix.dollar_row >> 7) == blk && (uint32_t) (ix.dollar_row & 127) <= r) res -= 1;
-    return res;
-}
-
-struct OccLine { uint64_t cnt, b0, b1, b2, b3; };
-
-__device__ __forceinline__ OccLine load_occ(const LrmIndexView &ix, uint64_t blk, uint32_t c) {
-    const LrmOccBlock *b = ix.occ + blk;
-    OccLine o;
-    o.cnt = b->cnt[c];
-    const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(&b->bits[0]);
-    const ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(&b->bits[2]);
-    o.b0 = v0.x; o.b1 = v0.y; o.b2 = v1.x; o.b3 = v1.y;
-    return o;
-}
-
-// rank(c, loc) = # of c in bwt[0..loc]  == _occ_access (fmidx.c:277-293)
-__device__ __forceinline__ void rank2(const LrmIndexView &ix, uint32_t c, uint64_t loc_a, uint64_t loc_b,
-                                      uint64_t &ra, uint64_t &rb) {
-    uint64_t blk_a = loc_a >> 7, blk_b = loc_b >> 7;
-    OccLine ob = load_occ(ix, blk_b, c);
-    rb = block_rank(ix, blk_b, ob.cnt, ob.b0, ob.b1, ob.b2, ob.b3, c, (uint32_t) (loc_b & 127));
-    if (blk_a == blk_b) {           // small intervals: one 64-B line serves both ranks
-        ra = block_rank(ix, blk_a, ob.cnt, ob.b0, ob.b1, ob.b2, ob.b3, c, (uint32_t) (loc_a & 127));
-    } else {
-        OccLine oa = load_occ(ix, blk_a, c);
-        ra = block_rank(ix, blk_a, oa.cnt, oa.b0, oa.b1, oa.b2, oa.b3, c, (uint32_t) (loc_a & 127));
-    }
+__device__ __forceinline__ uint64_t occ_rank(const LrmIndexView &ix, uint32_t c, uint64_t loc) {
+    const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(&ix.occ[loc >> 6].sym[c]);
+    const uint32_t r = (uint32_t) loc & 63u;
+    const uint64_t upto = r == 63u ? ~0ull : ((2ull << r) - 1ull);
+    return e.x + (uint64_t) __popcll(e.y & upto);
 }
 
 // lc_aln (lchash.c:89-104) + fmi_aln (fmidx.c:295-313) on the packed read.
@@ -117,8 +77,7 @@ __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t wi
     if (k == 0 && l == 0) return 0;
     for (int i = left - 1; i >= 0; --i) {
         uint32_t c = (uint32_t) (win >> (2 * i)) & 3u;
-        uint64_t ra, rb;
-        rank2(ix, c, k - 1, l, ra, rb);
+        const uint64_t ra = occ_rank(ix, c, k - 1), rb = occ_rank(ix, c, l);
         k = ix.c4[c] + ra + 1;
         l = ix.c4[c] + rb;
         if (k > l) break;
@@ -133,8 +92,7 @@ __device__ __forceinline__ uint64_t read_window(const uint64_t *__restrict__ wor
 }
 
 // ----------------------------------------------------------------------------------------
-// K1 seed_search: one lane per seed.  Work items of a read are (q, iter) with iter fastest,
-// so neighbouring lanes touch neighbouring read positions j = iter + q*P.
+// K1 seed_search: one lane per seed.  Work items of a read are (q, iter) with iter fastest.
 // rec[read][iter][q] = k | rr<<40  when 0 < rr < thres, else 0.
 // ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const uint64_t *__restrict__ reads2,
@@ -150,6 +108,10 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
     if (decided && decided[read]) return;
     const int P = seed_len + 1;
     const int np = phase_hi - phase_lo + 1;
+    // iter fastest: the 64 lanes of a wavefront hold 64 CONSECUTIVE read positions.  Neighbouring
+    // seeds overlap, so they share their fate (a sequencing error kills ~20 consecutive seeds, a clean
+    // stretch lets all of them run the full backward extension): wavefronts diverge little.  (q fastest
+    // would coalesce the record stores but was 26 % slower: every wavefront then mixes dead and live lanes.)
     uint32_t item = chunk * 256 + threadIdx.x;
     uint32_t q = item / (uint32_t) np;
     int iter = phase_lo + (int) (item % (uint32_t) np);

@@ -210,3 +210,4 @@ def test_blob_roundtrip_and_adopt(dev_indexes, gpu):
     b = mapper.seed_batch(d2, sc["reads"], sc["lens"])
     assert np.array_equal(a, b)
     d2.close()
+
