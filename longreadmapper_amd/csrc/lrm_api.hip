@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <algorithm>
 #include "lrm_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -32,6 +33,7 @@ extern "C" int lrm_device_count(void) {
 }
 
 static inline uint64_t align256(uint64_t x) { return (x + 255ull) & ~255ull; }
+#define LRM_LCX_MAX 4096    // capacity of the long-interval side table
 
 static void blob_layout(uint64_t length, int hlen, int mta_len, LrmBlobHeader *h) {
     memset(h, 0, sizeof(*h));
@@ -46,7 +48,8 @@ static void blob_layout(uint64_t length, int hlen, int mta_len, LrmBlobHeader *h
     h->con_len = length;
     uint64_t off = sizeof(LrmBlobHeader);
     h->off_occ = off;       off = align256(off + h->n_blocks * sizeof(LrmOccBlock));
-    h->off_lc = off;        off = align256(off + h->lc_entries * 16);
+    h->off_lc = off;        off = align256(off + h->lc_entries * 8);
+    h->off_lcx = off;       off = align256(off + LRM_LCX_MAX * 24);
     h->off_sa = off;        off = align256(off + h->sa_len * 8);
     h->off_content = off;   off = align256(off + h->con_len + 1);
     h->off_mta = off;       off = align256(off + (uint64_t) (mta_len > 0 ? mta_len : 1) * sizeof(LrmMtaDev));
@@ -115,16 +118,40 @@ extern "C" int lrm_index_pack_blob(const lrm_dna_fmi *fmi, const lrm_lc_hash *lc
     for (uint64_t b = (L + LRM_OCC_ROWS - 1) / LRM_OCC_ROWS; b < h.n_blocks; ++b)     // spare block(s): final counts
         for (int c = 0; c < 4; ++c) occ[b].sym[c].cnt = run[c];
 
-    // lc table, permuted to the LSB-first code
+    // lc table, permuted to the LSB-first code, 8 bytes per entry
     uint64_t *lc = (uint64_t *) (base + h.off_lc);
     const int hl = lch->hlen;
     const uint64_t ne = h.lc_entries;
+    std::vector<uint64_t> over;
+    uint64_t long_thr = 0xFFFFFFull;           // testing knob: send shorter intervals through the side table too
+    if (const char *e = getenv("LRM_LCX_THRESHOLD")) { long_thr = strtoull(e, nullptr, 0); if (long_thr < 1 || long_thr > 0xFFFFFFull) long_thr = 0xFFFFFFull; }
 #pragma omp parallel for schedule(static)
     for (uint64_t num = 0; num < ne; ++num) {
         uint64_t code = 0, t = num;
         for (int i = 0; i < hl; ++i) { code = (code << 2) | (t & 3); t >>= 2; }   // reverse the 2-bit groups
-        lc[2 * code] = lch->lc[2 * num];
-        lc[2 * code + 1] = lch->lc[2 * num + 1];
+        const uint64_t k = lch->lc[2 * num], l = lch->lc[2 * num + 1];
+        uint64_t e = 0;
+        if (!(k == 0 && l == 0)) {
+            uint64_t cnt = l >= k ? l - k + 1 : 0;
+            if (cnt == 0 || cnt >= long_thr || k >= (1ull << 40)) {
+                cnt = 0xFFFFFFull;
+#pragma omp critical
+                { over.push_back(code); over.push_back(k); over.push_back(l); }
+            }
+            e = (k & ((1ull << 40) - 1ull)) | (cnt << 40);
+        }
+        lc[code] = e;
+    }
+    if (over.size() / 3 > LRM_LCX_MAX) { lrm_set_error("too many long lchash intervals (%zu)", over.size() / 3); return -1; }
+    {
+        uint64_t *lcx = (uint64_t *) (base + h.off_lcx);
+        memset(lcx, 0xff, LRM_LCX_MAX * 24);
+        std::vector<size_t> ord(over.size() / 3);
+        for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
+        std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return over[3 * a] < over[3 * b]; });
+        for (size_t i = 0; i < ord.size(); ++i)
+            for (int f = 0; f < 3; ++f) lcx[3 * i + f] = over[3 * ord[i] + f];
+        h.n_lcx = ord.size();
     }
 
     uint64_t *sav = (uint64_t *) (base + h.off_sa);
@@ -149,6 +176,8 @@ static int make_handle(lrm_index **out, void *d_blob, uint64_t bytes, int device
     uint8_t *b = (uint8_t *) d_blob;
     ix->view.occ = (const LrmOccBlock *) (b + h.off_occ);
     ix->view.lc = (const uint64_t *) (b + h.off_lc);
+    ix->view.lcx = (const uint64_t *) (b + h.off_lcx);
+    ix->view.n_lcx = h.n_lcx;
     ix->view.sa = (const uint64_t *) (b + h.off_sa);
     ix->view.content = (const char *) (b + h.off_content);
     ix->view.mta = (const LrmMtaDev *) (b + h.off_mta);

@@ -11,10 +11,13 @@
 //                     reference layout, fmidx.c:277-293, needs an 8-B o[] read plus a <=32-B
 //                     byte-compare scan of bwt[] in a different array).  The '$' row sets no
 //                     mask bit, so it needs no special case.
-//   [lc table]     4^hlen entries {u64 k, u64 l}, indexed by the LSB-first 2-bit code of the
-//                  hlen-mer (base i at bits 2i..2i+1) so the kernel extracts the index as one
-//                  bit field of the packed read.  (reference: first base most significant,
-//                  lchash.c:36-49; the packer permutes.)
+//   [lc table]     4^hlen entries of 8 bytes, k | (l-k+1) << 40 (0 = absent), indexed by the
+//                  LSB-first 2-bit code of the hlen-mer (base i at bits 2i..2i+1) so the kernel
+//                  extracts the index as one bit field of the packed read.  Half the footprint of
+//                  the reference's {u64 k, u64 l} pairs (lchash.c:12-16): 128 MiB for hlen 12, which
+//                  stays resident in the 256 MiB Infinity Cache.  Intervals of >= 2^24-1 rows are
+//                  marked 0xFFFFFF and resolved through a small sorted side table [lcx].
+//                  (reference order: first base most significant, lchash.c:36-49; the packer permutes.)
 //   [sa]           u64 per row (values of sa_access, fmidx.c:18-33)
 //   [content]      the .cat text, 1 byte per base (GACT target side)
 //   [mta]          {u64 offset, u64 seq_len} per sequence (accaln.h:67-71 without names)
@@ -49,14 +52,17 @@ struct LrmBlobHeader {
     uint64_t off_occ, off_lc, off_sa, off_content, off_mta;
     uint64_t total_bytes;
     int32_t hlen, mta_len;
-    uint64_t reserved[13];
+    uint64_t off_lcx, n_lcx;   // side table of {code, k, l} for intervals too long for 24 bits
+    uint64_t reserved[11];
 };
 static_assert(sizeof(LrmBlobHeader) == 256, "header is 256 B");
 
 // What kernels receive by value.
 struct LrmIndexView {
     const LrmOccBlock *occ;
-    const uint64_t *lc;       // pairs
+    const uint64_t *lc;       // 8-byte entries
+    const uint64_t *lcx;      // {code, k, l} triples, sorted by code
+    uint64_t n_lcx;
     const uint64_t *sa;
     const char *content;
     const LrmMtaDev *mta;

@@ -59,6 +59,21 @@ __device__ __forceinline__ uint64_t occ_rank(const LrmIndexView &ix, uint32_t c,
     return e.x + (uint64_t) __popcll(e.y & upto);
 }
 
+// lc_access (lchash.c:12-16) on the 8-byte device entries
+__device__ __forceinline__ void lc_lookup(const LrmIndexView &ix, uint64_t code, uint64_t &k, uint64_t &l) {
+    const uint64_t e = ix.lc[code];
+    k = e & ((1ull << 40) - 1ull);
+    const uint64_t cnt = e >> 40;
+    l = k + cnt - 1;
+    if (e == 0) { k = 0; l = 0; }                                // absent hlen-mer
+    else if (cnt == 0xFFFFFFull) {                               // interval too long for 24 bits: side table
+        uint64_t lo = 0, hi = ix.n_lcx;
+        while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (ix.lcx[3 * mid] < code) lo = mid + 1; else hi = mid; }
+        k = ix.lcx[3 * lo + 1];
+        l = ix.lcx[3 * lo + 2];
+    }
+}
+
 // lc_aln (lchash.c:89-104) + fmi_aln (fmidx.c:295-313) on the packed read.
 // win: bases j.. of the read, 2 bits each, LSB first.  Returns rr; k,l as the reference
 // leaves them (also on failure).
@@ -66,10 +81,7 @@ __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t wi
                                              uint64_t &k, uint64_t &l) {
     int left = seed_len - ix.hlen;
     if (left >= 0) {
-        uint64_t code = (win >> (2 * left)) & ((1ull << (2 * ix.hlen)) - 1ull);
-        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(ix.lc + 2 * code);
-        k = e.x;
-        l = e.y;
+        lc_lookup(ix, (win >> (2 * left)) & ((1ull << (2 * ix.hlen)) - 1ull), k, l);
     } else {
         k = 1;
         l = ix.length - 1;
@@ -110,8 +122,9 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
     const int np = phase_hi - phase_lo + 1;
     // iter fastest: the 64 lanes of a wavefront hold 64 CONSECUTIVE read positions.  Neighbouring
     // seeds overlap, so they share their fate (a sequencing error kills ~20 consecutive seeds, a clean
-    // stretch lets all of them run the full backward extension): wavefronts diverge little.  (q fastest
-    // would coalesce the record stores but was 26 % slower: every wavefront then mixes dead and live lanes.)
+    // stretch lets all of them run the full backward extension): wavefronts diverge little.
+    // Measured alternatives that lost: q fastest (coalesced record stores, but every wavefront mixes
+    // dead and live lanes: +26 %), two seeds per lane (+26 %), lane refill from a work chunk (+13 %).
     uint32_t item = chunk * 256 + threadIdx.x;
     uint32_t q = item / (uint32_t) np;
     int iter = phase_lo + (int) (item % (uint32_t) np);
@@ -120,11 +133,12 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
     uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;   // alnmain.c:353 (fenced for len<s)
     uint64_t j = (uint64_t) iter + (uint64_t) q * (uint64_t) P;
     uint64_t *out = rec + (read * (uint64_t) P + (uint64_t) iter) * cap_q + q;
-    if (j >= jl) { *out = 0; return; }
+    if (j >= jl) { __builtin_nontemporal_store(0ull, out); return; }
     uint64_t win = read_window(reads2 + read * words_per_read, (uint32_t) j);
     uint64_t k, l;
     uint64_t rr = seed_one(ix, win, seed_len, k, l);
-    *out = (rr > 0 && rr < (uint64_t) thres) ? (k | (rr << 40)) : 0ull;
+    // streamed once, read once by the vote kernels: keep it out of the way of the index tables in L2 / MALL
+    __builtin_nontemporal_store((rr > 0 && rr < (uint64_t) thres) ? (k | (rr << 40)) : 0ull, out);
 }
 
 // debug tap: full (j, rr, k, l) per seed of one read, in (iter, q) order

@@ -211,3 +211,17 @@ def test_blob_roundtrip_and_adopt(dev_indexes, gpu):
     assert np.array_equal(a, b)
     d2.close()
 
+
+
+def test_long_interval_side_table(gpu, monkeypatch):
+    """lchash intervals too long for the 24-bit count of the 8-byte device entries go through a sorted
+    side table; the packer's threshold knob sends ordinary repeats there so the path is exercised."""
+    sc = workloads.scenario("repeats-ties")
+    oi = orc.OracleIndex.from_host_index(sc["hi"])
+    want, _ = oi.seed_batch(sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+    monkeypatch.setenv("LRM_LCX_THRESHOLD", "30")
+    di = index.DeviceIndex.upload(sc["hi"], gpu)
+    monkeypatch.delenv("LRM_LCX_THRESHOLD")
+    got = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+    assert np.array_equal(got, want)
+    di.close()
