@@ -31,6 +31,25 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def load_pmc_summary(args, n, Lr):
+    """HBM traffic per kernel from the committed rocprofv3 PMC passes of THIS workload (profiles/rNN/
+    pmc_summary.json, made by profiles/collect.sh + summarize_pmc.py); None for any other workload."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        w = d["workload"]
+        if (w["reads_per_gpu"], w["read_len"], w["seed_len"], w["thres"]) != (n, Lr, args.seed_len, args.thres):
+            return None
+        if args.ref_len != ECOLI_N or args.profile != "ont":
+            return None
+        return d["kernels"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,6 +73,8 @@ def main():
     rank, world, local = dist.init_process_group()
     assert world == args.gpus, "WORLD_SIZE %d != --gpus %d (launch N>1 with torch.distributed.run)" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
+    if os.environ.get("LRM_BENCH_ONE_DEVICE"):      # rehearsal: several ranks share cuda:0 (with LRM_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     gact = tuple(int(x) for x in args.gact.split(","))
@@ -108,7 +129,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ktimes = dm.timing() if not args.no_kernel_timing else {}
     dm.set_timing(False)
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if tdist.is_initialized() and tdist.get_backend() == "nccl" else "cpu")
     if world > 1:
         tdist.all_reduce(tt, op=tdist.ReduceOp.MAX)
     elapsed = float(tt.item())
@@ -174,33 +195,56 @@ def main():
     )
 
     # ---- per-kernel table and the roofline of the dominant kernel ----------------------------------
+    # algorithmic bytes per read base per kernel family; the three vote kernels share the SA bytes
+    alg_of = {"pack2bit_kernel": per_base["pack2bit"], "seed_search_kernel": per_base["seed_search"],
+              "gact_kernel": per_base["gact"]}
+    pmc = load_pmc_summary(args, n, Lr)
     kernels = {}
     dominant = None
+    vote_ms = sum(ms for name, (ms, _) in ktimes.items() if name.startswith("vote"))
     for name, (ms, launches) in ktimes.items():
         if launches == 0:
             continue
-        key = {"vote_wave": "vote", "vote_wave2": "vote", "vote_block": "vote"}.get(name.replace("_kernel", ""),
-                                                                                 name.replace("_kernel", ""))
-        alg = per_base.get(key) if not name.startswith("vote") else None
+        alg = alg_of.get(name)
+        if name.startswith("vote") and vote_ms > 0:
+            alg = per_base["vote"] * ms / vote_ms          # SA bytes apportioned by time over the vote tiers
         per_launch_bytes = alg * bases * args.steps / launches if alg else None
         avg_ms = ms / launches
-        kernels[name] = dict(ms_total=round(ms, 3), launches=launches, avg_ms=round(avg_ms, 4),
-                             algorithmic_bytes_per_launch=per_launch_bytes,
-                             achieved_GBps=(per_launch_bytes / (avg_ms * 1e-3) / 1e9) if per_launch_bytes else None)
+        k = dict(ms_total=round(ms, 3), launches=launches, avg_ms=round(avg_ms, 4),
+                 algorithmic_bytes_per_launch=per_launch_bytes,
+                 achieved_GBps=(per_launch_bytes / (avg_ms * 1e-3) / 1e9) if per_launch_bytes else None)
+        pk = pmc.get(name.replace("gact_kernel", "gact3_kernel")) if pmc else None
+        if pk:
+            k["traffic_bytes_per_launch"] = (pk["fetch_bytes"] + pk["write_bytes"]) / pk["launches_per_step"]
+            if pk.get("l2_hit") is not None and (pk["l2_hit"] + pk["l2_miss"]) > 0:
+                k["l2_hit_rate"] = pk["l2_hit"] / (pk["l2_hit"] + pk["l2_miss"])
+            if pk.get("valu_insts"):
+                k["valu_wave_insts_per_launch"] = pk["valu_insts"] / pk["launches_per_step"]
+        kernels[name] = k
         if dominant is None or ms > ktimes[dominant][0]:
             dominant = name
-    roofline = None
-    if dominant:
-        k = kernels[dominant]
+
+    def roofline_of(name):
+        k = kernels[name]
         ach = k["achieved_GBps"] or 0.0
-        roofline = dict(kernel=dominant, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=ach / HBM_PEAK_GBS, traffic=None,
-                        avg_launch_ms=k["avg_ms"], algorithmic_bytes_per_launch=k["algorithmic_bytes_per_launch"])
-        if dominant == "gact_kernel":
-            gcups = per_base["cells"] * bases * args.steps / (ktimes[dominant][0] * 1e-3) / 1e9
-            roofline["note"] = ("integer DP kernel: HBM fraction is small by construction "
-                                "(%.1f B/base algorithmic); %.0f GCUPS" % (per_base["gact"], gcups))
-            roofline["gcups"] = gcups
+        r = dict(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                 traffic=k.get("traffic_bytes_per_launch"), avg_launch_ms=k["avg_ms"],
+                 algorithmic_bytes_per_launch=k["algorithmic_bytes_per_launch"])
+        if "valu_wave_insts_per_launch" in k:
+            # integer VALU issue: one wave64 instruction per 4 cycles per SIMD, 1024 SIMDs, 2.4 GHz peak clock
+            peak_ips = 1024 * 2.4e9 / 4
+            r["valu_issue_frac"] = k["valu_wave_insts_per_launch"] / (k["avg_ms"] * 1e-3) / peak_ips
+        return r
+
+    roofline = roofline_of(dominant) if dominant else None
+    if dominant == "gact_kernel":
+        gcups = per_base["cells"] * bases * args.steps / (ktimes[dominant][0] * 1e-3) / 1e9
+        roofline["gcups"] = gcups
+        roofline["note"] = ("dominant kernel is the integer DP (gact): it is bound by VALU issue, not by HBM or MFMA -- "
+                            "its HBM fraction is small by construction (%.1f algorithmic B/base, %.0f cells/base); "
+                            "see valu_issue_frac and roofline_hbm_kernel for the HBM-gather-bound seed_search"
+                            % (per_base["gact"], per_base["cells"]))
+    roofline_hbm = roofline_of("seed_search_kernel") if "seed_search_kernel" in kernels else None
     total_bases = bases * world * args.steps
     out = dict(metric="aligned Gbp/sec", value=total_bases / elapsed / 1e9, unit="Gbp/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
@@ -209,7 +253,7 @@ def main():
                                     "%d x %d bp %s-profile reads per GPU" % (args.ref_len, n, Lr, args.profile),
                            seed_len=args.seed_len, thres=args.thres, gact_T=gact[0], gact_O=gact[1], gact_W=gact[2],
                            reads_per_gpu=n, read_len=Lr, parallelism="reads sharded, index replicated (1 RCCL bcast)"),
-               roofline=roofline, cpu_baseline=cpu, kernels=kernels,
+               roofline=roofline, roofline_hbm_kernel=roofline_hbm, cpu_baseline=cpu, kernels=kernels,
                algorithmic_bytes_per_base=per_base, stats=stats,
                index_broadcast_s=round(t_bcast, 3), speedup_vs_cpu=(total_bases / elapsed / 1e9) / cpu["value"])
     print(json.dumps(out), flush=True)

@@ -21,7 +21,8 @@ def init_process_group(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # LRM_DIST_BACKEND=gloo: rehearsal of the N>1 control flow on a box with fewer GPUs than ranks
+            backend = os.environ.get("LRM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -56,16 +57,20 @@ def broadcast_blob(blob, device=None, src=0):
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1:
         return blob
-    size = torch.zeros(1, dtype=torch.int64, device=device)
+    via_host = dist.get_backend() == "gloo" and device is not None and torch.device(device).type == "cuda"
+    cdev = torch.device("cpu") if via_host else device          # gloo rehearsal: stage through host memory
+    size = torch.zeros(1, dtype=torch.int64, device=cdev)
     if rank == src:
         size[0] = blob.numel()
     dist.broadcast(size, src=src)
     n = int(size.item())
-    if rank != src:
-        blob = torch.empty(n, dtype=torch.uint8, device=device)
+    if rank == src:
+        buf = blob.to(cdev) if via_host else blob
+    else:
+        buf = torch.empty(n, dtype=torch.uint8, device=cdev)
     for lo in range(0, n, BCAST_CHUNK):
-        dist.broadcast(blob[lo:min(lo + BCAST_CHUNK, n)], src=src)
-    return blob
+        dist.broadcast(buf[lo:min(lo + BCAST_CHUNK, n)], src=src)
+    return buf.to(device) if via_host else buf
 
 
 def gather_in_order(local_arrays, slices):

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/<tag>/ (written by profiles/collect.sh) into the committed summaries:
+profiles/<tag>/kernel_stats.csv (rocprofv3 --kernel-trace --stats), bench_default.json,
+pmc_summary.json (per kernel, per timed step of the default workload) and README.md."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles", tag)
+os.makedirs(dst, exist_ok=True)
+
+LAUNCHES_PER_STEP = {"pack2bit_kernel": 1, "seed_search_kernel": 2, "vote_wave_kernel": 2, "vote_wave2_kernel": 4,
+                     "vote_block_kernel": 2, "decide_kernel": 2, "locus_resolve_kernel": 1, "revcomp_kernel": 1,
+                     "gact3_kernel": 1, "gact_kernel": 1}
+
+
+def short(name):
+    n = name.replace("void ", "").split("(")[0].split("<")[0]
+    return n
+
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, "kernel_stats.csv"))
+shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, "bench_default.json"))
+
+per_kernel = collections.defaultdict(dict)
+for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
+    rows = list(csv.DictReader(open(f)))
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    order = collections.defaultdict(list)
+    for r in rows:
+        k = short(r["Kernel_Name"])
+        d = int(r["Dispatch_Id"])
+        per[(k, d)][r["Counter_Name"]] += float(r["Counter_Value"])
+        per[(k, d)]["ms"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        if d not in order[k]:
+            order[k].append(d)
+    for k, ds in order.items():
+        if k not in LAUNCHES_PER_STEP:
+            continue
+        sel = ds[-LAUNCHES_PER_STEP[k]:]          # the timed step is the last one (one warm-up step before it)
+        agg = collections.defaultdict(float)
+        for d in sel:
+            for c, v in per[(k, d)].items():
+                agg[c] += v
+        per_kernel[k].update(agg)
+        per_kernel[k]["launches_per_step"] = LAUNCHES_PER_STEP[k]
+
+bench = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
+summary = {"workload": bench["config"], "note": "per timed step (1 Gbp); FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them",
+           "kernels": {}}
+lines = ["| kernel | launches/step | ms/step (PMC run) | FETCH GB | WRITE GB | L2 hit | VALU wave-instr | SQ_WAIT_ANY / SQ_WAVE_CYCLES |",
+         "|---|---|---|---|---|---|---|---|"]
+for k, v in per_kernel.items():
+    hit, miss = v.get("TCC_HIT_sum", 0), v.get("TCC_MISS_sum", 0)
+    e = dict(launches_per_step=int(v["launches_per_step"]), ms=v.get("ms"), fetch_bytes=v.get("FETCH_SIZE", 0) * 1024,
+             write_bytes=v.get("WRITE_SIZE", 0) * 1024, l2_hit=hit, l2_miss=miss, valu_insts=v.get("SQ_INSTS_VALU"),
+             salu_insts=v.get("SQ_INSTS_SALU"), vmem_rd=v.get("SQ_INSTS_VMEM_RD"), wave_cycles_q=v.get("SQ_WAVE_CYCLES"),
+             wait_any_q=v.get("SQ_WAIT_ANY"), active_valu_q=v.get("SQ_ACTIVE_INST_VALU"), waves=v.get("SQ_WAVES"))
+    summary["kernels"][k] = e
+    lines.append("| %s | %d | %.2f | %.2f | %.2f | %s | %s | %s |" % (
+        k, e["launches_per_step"], e["ms"] or 0, e["fetch_bytes"] / 1e9, e["write_bytes"] / 1e9,
+        ("%.0f %%" % (100 * hit / (hit + miss))) if hit + miss else "-",
+        ("%.3g" % e["valu_insts"]) if e["valu_insts"] else "-",
+        ("%.0f %%" % (100 * e["wait_any_q"] / e["wave_cycles_q"])) if e["wave_cycles_q"] else "-"))
+json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+
+kt = []
+if stats:
+    for r in csv.DictReader(open(stats[0])):
+        kt.append("| %s | %s | %.3f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e6, r["Percentage"]))
+with open(os.path.join(dst, "README.md"), "w") as f:
+    f.write("# Profiles %s — default `bench.py` workload on one MI355X\n\n" % tag)
+    f.write("`bench_default.json`: the JSON line of `python bench.py` (5 steps, 1 warm-up).\n\n")
+    f.write("value = **%.2f Gbp/s**, %.1f ms per 1-Gbp step; CPU oracle on %d host cores: %.4f Gbp/s (x%.0f).\n\n"
+            % (bench["value"], bench["ms_per_step"], bench["cpu_baseline"]["cores"], bench["cpu_baseline"]["value"],
+               bench["speedup_vs_cpu"]))
+    f.write("## HIP-event timing inside bench.py (timed steps)\n\n| kernel | launches | avg ms |\n|---|---|---|\n")
+    for k, v in bench["kernels"].items():
+        f.write("| %s | %d | %.3f |\n" % (k, v["launches"], v["avg_ms"]))
+    f.write("\n## rocprofv3 --kernel-trace --stats of `bench.py --steps 3 --warmup 1 --cpu-seconds 0` (`kernel_stats.csv`)\n\n")
+    f.write("| kernel | calls | avg ms | % |\n|---|---|---|---|\n" + "\n".join(kt) + "\n")
+    f.write("\n## PMC passes (`pmc_summary.json`; separate runs, one timed step each)\n\n" + "\n".join(lines) + "\n")
+print(open(os.path.join(dst, "README.md")).read())
