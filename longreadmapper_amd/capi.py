@@ -63,6 +63,11 @@ class Stats(C.Structure):
                 ("reads_decided_phase0", C.c_uint64), ("gact_tiles", C.c_uint64)]
 
 
+class ReadBatch(C.Structure):          # lrm_io_host.h
+    _fields_ = [("n", C.c_uint64), ("stride", C.c_uint64), ("max_len", C.c_uint32), ("seqs", C.c_void_p),
+                ("lens", u32p), ("names", C.POINTER(C.c_char_p)), ("quals", C.POINTER(C.c_char_p))]
+
+
 class HostIndex(C.Structure):          # lrm_index_host.h
     _fields_ = [("fmi", DnaFmi), ("lch", LcHash), ("sa", SaMem), ("content", C.c_void_p),
                 ("con_len", C.c_uint64), ("mta", C.POINTER(MtaEntry)), ("mta_len", C.c_int)]
@@ -124,6 +129,17 @@ SYMBOLS = {
     "lrm_mta_read": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(MtaEntry))]),
     "lrm_mta_free": (None, [C.POINTER(MtaEntry), C.c_int]),
     "lrm_accidx": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_uint64]),
+    # lrm_io_host.h
+    "lrm_reader_open": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p]),
+    "lrm_reader_next": (C.c_int64, [C.c_void_p, C.c_uint64, C.POINTER(ReadBatch)]),
+    "lrm_read_batch_free": (None, [C.POINTER(ReadBatch)]),
+    "lrm_reader_close": (None, [C.c_void_p]),
+    "lrm_parse_cigar": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "lrm_sam_header": (C.c_void_p, [C.POINTER(MtaEntry), C.c_int, C.c_long, u64p]),
+    "lrm_sam_format": (C.c_void_p, [C.POINTER(ReadBatch), C.POINTER(MtaEntry), C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_uint64, u64p]),
+    "lrm_free": (None, [C.c_void_p]),
+    "lrm_accaln": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, Params, GactParams, C.c_int, C.c_long, u64p, u64p]),
 }
 
 

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared():
     names = set()
-    for h in ("lrm_accel.h", "lrm_index_host.h"):
+    for h in ("lrm_accel.h", "lrm_index_host.h", "lrm_io_host.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names |= set(re.findall(r"\b(lrm_[a-z0-9_]+)\s*\(", src))
