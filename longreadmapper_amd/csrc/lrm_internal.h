@@ -18,6 +18,9 @@
 //                  stays resident in the 256 MiB Infinity Cache.  Intervals of >= 2^24-1 rows are
 //                  marked 0xFFFFFF and resolved through a small sorted side table [lcx].
 //                  (reference order: first base most significant, lchash.c:36-49; the packer permutes.)
+//   [lc bitmap]    1 bit per hlen-mer (2 MiB for hlen 12): ~40 % of the seeds of a noisy read carry an
+//                  absent hlen-mer; they are answered from this L2-resident bitmap instead of a
+//                  random 64-byte fetch into the 128 MiB table.
 //   [sa]           u64 per row (values of sa_access, fmidx.c:18-33)
 //   [content]      the .cat text, 1 byte per base (GACT target side)
 //   [mta]          {u64 offset, u64 seq_len} per sequence (accaln.h:67-71 without names)
@@ -53,7 +56,8 @@ struct LrmBlobHeader {
     uint64_t total_bytes;
     int32_t hlen, mta_len;
     uint64_t off_lcx, n_lcx;   // side table of {code, k, l} for intervals too long for 24 bits
-    uint64_t reserved[11];
+    uint64_t off_lcb;          // presence bitmap of the lc table (1 bit per hlen-mer)
+    uint64_t reserved[10];
 };
 static_assert(sizeof(LrmBlobHeader) == 256, "header is 256 B");
 
@@ -63,6 +67,7 @@ struct LrmIndexView {
     const uint64_t *lc;       // 8-byte entries
     const uint64_t *lcx;      // {code, k, l} triples, sorted by code
     uint64_t n_lcx;
+    const uint32_t *lcb;      // presence bitmap: 2 MiB for hlen 12, L2-resident; absent hlen-mers never touch lc[]
     const uint64_t *sa;
     const char *content;
     const LrmMtaDev *mta;

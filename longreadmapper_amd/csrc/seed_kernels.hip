@@ -59,6 +59,18 @@ __device__ __forceinline__ uint64_t occ_rank(const LrmIndexView &ix, uint32_t c,
     return e.x + (uint64_t) __popcll(e.y & upto);
 }
 
+// the two ranks of one backward step; after the table lookup most intervals are a handful of rows,
+// so k-1 and l usually fall into the same 64-row block and ONE 16-byte request serves both
+__device__ __forceinline__ void occ_rank2(const LrmIndexView &ix, uint32_t c, uint64_t loc_a, uint64_t loc_b,
+                                          uint64_t &ra, uint64_t &rb) {
+    const ulonglong2 eb = *reinterpret_cast<const ulonglong2 *>(&ix.occ[loc_b >> 6].sym[c]);
+    ulonglong2 ea = eb;
+    if ((loc_a >> 6) != (loc_b >> 6)) ea = *reinterpret_cast<const ulonglong2 *>(&ix.occ[loc_a >> 6].sym[c]);
+    const uint32_t qa = (uint32_t) loc_a & 63u, qb = (uint32_t) loc_b & 63u;
+    ra = ea.x + (uint64_t) __popcll(ea.y & (qa == 63u ? ~0ull : ((2ull << qa) - 1ull)));
+    rb = eb.x + (uint64_t) __popcll(eb.y & (qb == 63u ? ~0ull : ((2ull << qb) - 1ull)));
+}
+
 // lc_access (lchash.c:12-16) on the 8-byte device entries
 __device__ __forceinline__ void lc_lookup(const LrmIndexView &ix, uint64_t code, uint64_t &k, uint64_t &l) {
     const uint64_t e = ix.lc[code];
@@ -89,7 +101,8 @@ __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t wi
     if (k == 0 && l == 0) return 0;
     for (int i = left - 1; i >= 0; --i) {
         uint32_t c = (uint32_t) (win >> (2 * i)) & 3u;
-        const uint64_t ra = occ_rank(ix, c, k - 1), rb = occ_rank(ix, c, l);
+        uint64_t ra, rb;
+        occ_rank2(ix, c, k - 1, l, ra, rb);
         k = ix.c4[c] + ra + 1;
         l = ix.c4[c] + rb;
         if (k > l) break;
@@ -97,10 +110,13 @@ __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t wi
     return k > l ? 0 : l - k + 1;
 }
 
+struct __attribute__((aligned(8))) WordPair { uint64_t a, b; };
+
 __device__ __forceinline__ uint64_t read_window(const uint64_t *__restrict__ words, uint32_t j) {
     uint32_t wi = j >> 5, sh = (j & 31) * 2;
-    uint64_t w0 = words[wi], w1 = words[wi + 1];
-    return sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+    WordPair w;                                           // one 16-byte request instead of two 8-byte ones
+    __builtin_memcpy(&w, words + wi, sizeof(w));
+    return sh ? ((w.a >> sh) | (w.b << (64 - sh))) : w.a;
 }
 
 // ----------------------------------------------------------------------------------------
