@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ECOLI_N = 4_641_652
+CHR1_N = 248_956_422
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -249,8 +250,10 @@ def main():
     out = dict(metric="aligned Gbp/sec", value=total_bases / elapsed / 1e9, unit="Gbp/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u8/u64 integer", data="synthetic",
-               config=dict(workload="E. coli K-12 sized synthetic reference (%d bp, 5%% planted repeats), "
-                                    "%d x %d bp %s-profile reads per GPU" % (args.ref_len, n, Lr, args.profile),
+               config=dict(workload="%s synthetic reference (%d bp, 5%% planted repeats), "
+                                    "%d x %d bp %s-profile reads per GPU"
+                                    % ({ECOLI_N: "E. coli K-12 sized", CHR1_N: "human chr1 sized"}.get(args.ref_len, "custom"),
+                                       args.ref_len, n, Lr, args.profile),
                            seed_len=args.seed_len, thres=args.thres, gact_T=gact[0], gact_O=gact[1], gact_W=gact[2],
                            reads_per_gpu=n, read_len=Lr, parallelism="reads sharded, index replicated (1 RCCL bcast)"),
                roofline=roofline, roofline_hbm_kernel=roofline_hbm, cpu_baseline=cpu, kernels=kernels,
