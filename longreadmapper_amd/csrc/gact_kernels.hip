@@ -643,6 +643,145 @@ __global__ __launch_bounds__(256) void gact3_kernel(const char *__restrict__ rea
     if (lane == 0) atomicAdd(&counters->gact_tiles, (unsigned long long) tiles);
 }
 
+// ----------------------------------------------------------------------------------------
+// GACT, wide bands (128 < W <= 1024, e.g. the full-tile band W = T of the config-4 sweep).
+// Same sweep as gact_kernel, but every lane owns DPL diagonal pairs: diagonal index x = lane + 64*g
+// (g < DPL), d = 2x - 64*DPL (+1 on odd anti-diagonals).  The neighbour of a group's edge lane is the
+// opposite edge lane of the adjacent group (one v_readlane per group and step).  One wavefront per
+// workgroup: the traceback of a wide band needs up to 128 KiB of LDS.  Simple form (32-bit scores,
+// one read per wavefront); the packed two-read kernel covers the default band.
+// ----------------------------------------------------------------------------------------
+template <int DPL>
+__global__ __launch_bounds__(64) void gact_wide_kernel(const char *__restrict__ reads, uint64_t stride,
+                                                       const uint32_t *__restrict__ lens,
+                                                       const lrm_seq_meta *__restrict__ meta,
+                                                       const int32_t *__restrict__ meta_r,
+                                                       const char *__restrict__ content,
+                                                       const uint32_t *__restrict__ tlens, uint64_t n_reads,
+                                                       int T, int O, int W, uint8_t *__restrict__ store,
+                                                       uint64_t store_stride, int32_t *__restrict__ n_ops_out,
+                                                       int32_t *__restrict__ score_out, LrmDevCounters *counters) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int NX = 64 * DPL;                   // diagonal indices per parity
+    constexpr int HWX = NX;                        // d = 2x - HWX (+1)
+    constexpr int PADW = NX / 2 + 40;              // guard bytes on both sides of the staged sequences
+    const int lane = threadIdx.x & 63;
+    const uint64_t read = blockIdx.x;
+    if (read >= n_reads) return;
+    if (!meta_r[read]) {
+        if (lane == 0) { n_ops_out[read] = 0; score_out[read] = -1; }
+        return;
+    }
+    const int cap = T - O, lim2 = 2 * cap;
+    const int tb_words = ((lim2 - 1) >> 4) + 1;
+    const int seq_bytes = (T + 2 * PADW + 15) & ~15;
+    uint32_t *tb = reinterpret_cast<uint32_t *>(smem);
+    uint8_t *qbuf = smem + (size_t) tb_words * NX * 4 + PADW;
+    uint8_t *dbuf = qbuf + seq_bytes;
+    uint8_t *opsbuf = smem + (size_t) tb_words * NX * 4 + 2 * (size_t) seq_bytes;
+
+    const int n = __builtin_amdgcn_readfirstlane((int) lens[read]);
+    const int m = tlens ? __builtin_amdgcn_readfirstlane((int) tlens[read]) : n;
+    const uint8_t *q = reinterpret_cast<const uint8_t *>(reads) + read * stride;
+    const uint8_t *d = reinterpret_cast<const uint8_t *>(content) + meta[read].loc;
+    uint8_t *ops_out = store + read * store_stride;
+    const int hw = W / 2;
+    const int s_hi = tb_words * 16 - 1;
+
+    int i = 0, j = 0, nops = 0, score = 0;
+    unsigned tiles = 0;
+    while (i < n && j < m) {
+        const int tq = (n - i) < T ? (n - i) : T;
+        const int tt = (m - j) < T ? (m - j) : T;
+        const bool last = (i + tq == n);
+        tiles++;
+        for (int x = lane; x < tq; x += 64) qbuf[x] = q[i + x];
+        for (int x = lane; x < tt; x += 64) dbuf[x] = d[j + x];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        int r1[DPL], r2[DPL], eE[DPL], eO[DPL];
+        bool inE[DPL], inO[DPL];
+        uint32_t acc[DPL];
+#pragma unroll
+        for (int g = 0; g < DPL; ++g) {
+            const int x = lane + 64 * g, dE = 2 * x - HWX, dO = dE + 1;
+            r1[g] = GACT_NEG; r2[g] = GACT_NEG; acc[g] = 0;
+            eE[g] = min(2 * tq + dE, 2 * tt - dE);
+            eO[g] = min(2 * tq + dO, 2 * tt - dO);
+            inE[g] = dE >= -hw && dE < hw;
+            inO[g] = dO >= -hw && dO < hw;
+        }
+        for (int s = tq + tt; s >= 0; --s) {
+            const bool odd = s & 1;
+            const bool track = s <= s_hi;
+            int nr[DPL];
+#pragma unroll
+            for (int g = 0; g < DPL; ++g) {
+                const int x = lane + 64 * g;
+                // even: a = s/2 + HWX/2 - x, b = s/2 - HWX/2 + x ; odd: a = (s-1)/2 + HWX/2 - x, b = (s-1)/2 - HWX/2 + 1 + x
+                const int h = odd ? (s - 1) / 2 : s / 2;
+                const int a = h + HWX / 2 - x, b = h - HWX / 2 + x + (odd ? 1 : 0);
+                const uint32_t qc = qbuf[a], dc = dbuf[b];
+                int ins, del;
+                if (!odd) {      // INS neighbour = diagonal index x-1 one step ago, DEL = own
+                    const int fill = g > 0 ? __builtin_amdgcn_readlane(r1[g > 0 ? g - 1 : 0], 63) : GACT_NEG;
+                    ins = dpp_from_lower(r1[g], fill);
+                    del = r1[g];
+                } else {         // INS = own, DEL = diagonal index x+1 one step ago
+                    const int fill = g + 1 < DPL ? __builtin_amdgcn_readlane(r1[g + 1 < DPL ? g + 1 : g], 0) : GACT_NEG;
+                    ins = r1[g];
+                    del = dpp_from_upper(r1[g], fill);
+                }
+                uint32_t a2 = acc[g];
+                nr[g] = gact_cell<true, false>(r2[g], ins, del, qc, dc, s >= (odd ? eO[g] : eE[g]),
+                                               odd ? inO[g] : inE[g], a2);
+                if (track) acc[g] = a2;
+            }
+#pragma unroll
+            for (int g = 0; g < DPL; ++g) {
+                r2[g] = r1[g]; r1[g] = nr[g];
+                if (track && (s & 15) == 0) tb[(s >> 4) * NX + lane + 64 * g] = acc[g];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        int a = 0, b = 0, cnt = 0;
+        while (a < tq && b < tt && (last ? (a + b < lim2) : (a < cap && b < cap))) {
+            const int sw = a + b, dd = b - a;
+            const uint32_t word = __builtin_amdgcn_readfirstlane(tb[(sw >> 4) * NX + ((dd + HWX) >> 1)]);
+            const uint32_t p = (word >> (2 * (sw & 15))) & 3u;
+            uint8_t op;
+            if (p == 0u || p == 3u) { op = p == 0u ? '=' : 'X'; score += p == 3u ? 1 : 0; a++; b++; }
+            else if (p == 1u) { op = 'I'; score++; a++; }
+            else { op = 'D'; score++; b++; }
+            if (lane == 0) opsbuf[cnt] = op;
+            cnt++;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int x = lane; x < cnt; x += 64) ops_out[nops + x] = opsbuf[x];
+        nops += cnt;
+        i += a;
+        j += b;
+        if (a + b == 0) { score = -1; break; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (score >= 0 && i < n) {
+        int rest = n - i;
+        for (int x = lane; x < rest; x += 64) ops_out[nops + x] = 'I';
+        nops += rest;
+        score += rest;
+    }
+    if (lane == 0) {
+        n_ops_out[read] = score >= 0 ? nops : 0;
+        score_out[read] = score;
+        atomicAdd(&counters->gact_tiles, (unsigned long long) tiles);
+    }
+}
+
 typedef void (*gact_fn_t)(const char *, uint64_t, const uint32_t *, const lrm_seq_meta *, const int32_t *,
                           const char *, const uint32_t *, uint64_t, int, int, int, uint8_t *, uint64_t, int32_t *,
                           int32_t *, LrmDevCounters *);
@@ -654,6 +793,24 @@ static int gact_launch(lrm_gact_params gp, uint64_t n, hipStream_t stream, const
                        const uint32_t *lens, const lrm_seq_meta *meta, const int32_t *meta_r, const char *content,
                        const uint32_t *tlens, uint8_t *store, uint64_t store_stride, int32_t *n_ops, int32_t *score,
                        LrmDevCounters *counters) {
+    if (gp.W > 128) {
+        int dpl = gp.W <= 256 ? 2 : gp.W <= 512 ? 4 : 8;
+        const int nx = 64 * dpl, padw = nx / 2 + 40;
+        const int tbw = ((2 * (gp.T - gp.O) - 1) >> 4) + 1;
+        const int seqb = (gp.T + 2 * padw + 15) & ~15;
+        size_t shw = (size_t) tbw * nx * 4 + 2 * (size_t) seqb + (((size_t) 2 * (gp.T - gp.O) + 15) & ~(size_t) 15);
+        if (shw > 160 * 1024) { lrm_set_error("GACT T=%d O=%d W=%d needs %zu B of LDS (> 160 KiB)", gp.T, gp.O, gp.W, shw); return -1; }
+        gact_fn_t fw = dpl == 2 ? gact_wide_kernel<2> : dpl == 4 ? gact_wide_kernel<4> : gact_wide_kernel<8>;
+        if (shw > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fw),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) shw);
+            if (e != hipSuccess) { lrm_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", shw, hipGetErrorString(e)); return -1; }
+        }
+        if (n > 0x7fffffffull) { lrm_set_error("gact grid too large: split the batch"); return -1; }
+        hipLaunchKernelGGL(fw, dim3((uint32_t) n), dim3(64), shw, stream, reads, stride, lens, meta, meta_r, content,
+                           tlens, n, gp.T, gp.O, gp.W, store, store_stride, n_ops, score, counters);
+        return 0;
+    }
     static int impl = -1;
     if (impl < 0) { const char *e = getenv("LRM_GACT_IMPL"); impl = e ? atoi(e) : 3; }
     static int dbg3 = -1;
@@ -697,8 +854,8 @@ int lrm_launch_extend(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint64_t
     if (gp.T == 0 && gp.O == 0 && gp.W == 0) {
         gp.T = LRM_GACT_T_DEFAULT; gp.O = LRM_GACT_O_DEFAULT; gp.W = LRM_GACT_W_DEFAULT;
     }
-    if (gp.T < 16 || gp.T > 512 || gp.O < 0 || gp.O >= gp.T || gp.W < 2 || (gp.W & 1) || gp.W > 128) {
-        lrm_set_error("unsupported GACT parameters T=%d O=%d W=%d (need 16<=T<=512, 0<=O<T, even 2<=W<=128)",
+    if (gp.T < 16 || gp.T > 512 || gp.O < 0 || gp.O >= gp.T || gp.W < 2 || (gp.W & 1) || gp.W > 1024) {
+        lrm_set_error("unsupported GACT parameters T=%d O=%d W=%d (need 16<=T<=512, 0<=O<T, even 2<=W<=1024)",
                       gp.T, gp.O, gp.W);
         return -1;
     }
@@ -741,7 +898,7 @@ extern "C" int lrm_debug_gact(const char *q, int n, const char *d, int m, lrm_ga
     if (gp.T == 0 && gp.O == 0 && gp.W == 0) {
         gp.T = LRM_GACT_T_DEFAULT; gp.O = LRM_GACT_O_DEFAULT; gp.W = LRM_GACT_W_DEFAULT;
     }
-    if (gp.T < 16 || gp.T > 512 || gp.O < 0 || gp.O >= gp.T || gp.W < 2 || (gp.W & 1) || gp.W > 128) {
+    if (gp.T < 16 || gp.T > 512 || gp.O < 0 || gp.O >= gp.T || gp.W < 2 || (gp.W & 1) || gp.W > 1024) {
         lrm_set_error("unsupported GACT parameters T=%d O=%d W=%d", gp.T, gp.O, gp.W);
         return -1;
     }

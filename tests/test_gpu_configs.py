@@ -1,8 +1,7 @@
 """BASELINE.json configs other than the bench line, as parity cases at a size the CPU oracle finishes in
 seconds: PacBio-CLR 15 kbp reads (config 2's read profile), 10 kbp ONT reads against a multi-sequence
 reference with planted repeats (config 3's shape), and 100 kbp ultra-long reads with the GACT
-tile / overlap / band sweep of config 4 (W = T needs more than one diagonal pair per lane: not built yet,
-the kernel rejects it -- see DESIGN.md)."""
+tile / overlap / band sweep of config 4, including the full-tile band W = T."""
 import numpy as np
 import pytest
 
@@ -60,16 +59,16 @@ def test_ont_10k_multi_sequence_with_repeats(ref3):
 
 
 @pytest.mark.parametrize("T,O,W", [(128, 32, 32), (128, 64, 64), (256, 64, 128), (256, 120, 64), (320, 120, 32),
-                                   (320, 32, 128), (512, 120, 128), (512, 64, 64)])
+                                   (320, 32, 128), (512, 120, 128), (512, 64, 64),
+                                   (128, 32, 128), (256, 64, 256), (320, 120, 320), (512, 120, 512)])   # ... and W = T
 def test_ultralong_100k_gact_sweep(ref3, T, O, W):
     seqs, hi, di, oi = ref3
     r = synth.reads(seqs, 6, 100_000, synth.ONT, seed=17)
     _compare(di, oi, r["reads"], r["lens"], (T, O, W))
 
 
-def test_full_band_is_rejected_not_approximated(ref3):
+def test_largest_tile_and_band(ref3):
+    """T = 512, O = 0, W = 1024: the largest traceback the kernel supports (134 KiB of LDS per wavefront)."""
     seqs, hi, di, oi = ref3
-    r = synth.reads(seqs, 2, 2_000, synth.ONT, seed=19)
-    best = mapper.seed_batch(di, r["reads"], r["lens"])
-    with pytest.raises(capi.LrmError, match="unsupported GACT"):
-        mapper.extend_batch(di, r["reads"].copy(), r["lens"], best, (320, 120, 320))
+    r = synth.reads(seqs, 8, 3_000, synth.ONT, seed=19)
+    _compare(di, oi, r["reads"], r["lens"], (512, 0, 1024))

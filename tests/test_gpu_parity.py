@@ -51,7 +51,8 @@ def _mutate(rng, s, sub, ins, dele):
 
 
 GACT_PARAMS = [(320, 120, 128), (128, 32, 64), (64, 16, 32), (16, 0, 2), (320, 120, 20), (512, 120, 128),
-               (100, 99, 128), (33, 7, 66), (320, 0, 128)]
+               (100, 99, 128), (33, 7, 66), (320, 0, 128),
+               (320, 120, 320), (128, 32, 256), (64, 16, 600), (200, 40, 1024)]      # wide bands: gact_wide_kernel
 
 
 @pytest.mark.parametrize("T,O,W", GACT_PARAMS)
@@ -79,7 +80,7 @@ def test_gact_rejects_unsupported_params(gpu):
     q = np.frombuffer(b"ACGT", dtype=np.uint8)
     ops = np.zeros(16, dtype=np.uint8)
     a, b = C.c_int(), C.c_int()
-    for gp in ((320, 320, 128), (320, 120, 129), (8, 0, 8), (320, 120, 256)):
+    for gp in ((320, 320, 128), (320, 120, 129), (8, 0, 8), (320, 120, 1026)):
         rc = capi.lib.lrm_debug_gact(q.ctypes.data, 4, q.ctypes.data, 4, capi.GactParams(*gp), ops.ctypes.data,
                                      C.byref(a), C.byref(b), 0)
         assert rc < 0 and b"unsupported GACT" in capi.lib.lrm_last_error()
