@@ -198,7 +198,7 @@ def main():
     # ---- per-kernel table and the roofline of the dominant kernel ----------------------------------
     # algorithmic bytes per read base per kernel family; the three vote kernels share the SA bytes
     alg_of = {"pack2bit_kernel": per_base["pack2bit"], "seed_search_kernel": per_base["seed_search"],
-              "gact_kernel": per_base["gact"]}
+              "gact_kernel": per_base["gact"], "gact_bs_kernel": per_base["gact"], "bs_pack_reads_kernel": 1.25}
     pmc = load_pmc_summary(args, n, Lr)
     kernels = {}
     dominant = None
@@ -238,7 +238,7 @@ def main():
         return r
 
     roofline = roofline_of(dominant) if dominant else None
-    if dominant == "gact_kernel":
+    if dominant in ("gact_kernel", "gact_bs_kernel"):
         gcups = per_base["cells"] * bases * args.steps / (ktimes[dominant][0] * 1e-3) / 1e9
         roofline["gcups"] = gcups
         roofline["note"] = ("dominant kernel is the integer DP (gact): it is bound by VALU issue, not by HBM or MFMA -- "

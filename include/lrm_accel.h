@@ -176,10 +176,11 @@ int lrm_workspace_stats(lrm_workspace *ws, lrm_stats *out, void *stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (bench bookkeeping).
  * Kernel order: pack2bit, seed_search, vote_wave (tier 1), vote_wave2 (tier 2), decide, locus_resolve,
- * revcomp, gact, vote_block (tier 3).
+ * revcomp, gact (byte kernels), vote_block (tier 3), bs_pack_reads, gact_bs (bit-sliced kernel).
  * lrm_workspace_timing synchronises the stream, ADDS the elapsed milliseconds and launch counts
- * of everything recorded since the last call into ms[9] / launches[9], and resets the record. */
-#define LRM_N_KERNELS 9
+ * of everything recorded since the last call into ms[LRM_N_KERNELS] / launches[LRM_N_KERNELS], and
+ * resets the record. */
+#define LRM_N_KERNELS 11
 int lrm_workspace_set_timing(lrm_workspace *ws, int enable);
 int lrm_workspace_timing(lrm_workspace *ws, double *ms, uint64_t *launches, void *stream);
 const char *lrm_kernel_name(int kernel);

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 
-ACCEL_SRCS = ["lrm_api.hip", "seed_kernels.hip", "gact_kernels.hip", "index_host.cpp", "io_host.cpp"]
+ACCEL_SRCS = ["lrm_api.hip", "seed_kernels.hip", "gact_kernels.hip", "gact_bs_kernels.hip", "index_host.cpp", "io_host.cpp"]
 ACCEL_DEPS = ACCEL_SRCS + ["lrm_internal.h", "../../include/lrm_accel.h", "../../include/lrm_index_host.h",
                            "../../include/lrm_io_host.h"]
 ACCEL_LIB = os.path.join(HERE, "liblrm_accel.so")

@@ -146,7 +146,8 @@ __global__ __launch_bounds__(256) void gact_kernel(const char *__restrict__ read
                                                    const uint32_t *__restrict__ tlens, uint64_t n_reads,
                                                    int T, int O, int W, uint8_t *__restrict__ store,
                                                    uint64_t store_stride, int32_t *__restrict__ n_ops_out,
-                                                   int32_t *__restrict__ score_out, LrmDevCounters *counters) {
+                                                   int32_t *__restrict__ score_out, LrmDevCounters *counters,
+                                                   const uint32_t *__restrict__ only) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // everything derived from the wave id is wave-uniform: keep it in SGPRs so that loop control
     // and the traceback walk run on the scalar unit
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(256) void gact_kernel(const char *__restrict__ read
     const int lane = threadIdx.x & 63;
     const uint64_t read = (uint64_t) blockIdx.x * 4 + (uint64_t) wave;
     if (read >= n_reads) return;
+    if (only && !only[read]) return;           // second launch behind the bit-sliced kernel: flagged reads only
     if (!meta_r[read]) {                       // fenced: no extension (reference would read garbage)
         if (lane == 0) { n_ops_out[read] = 0; score_out[read] = -1; }
         return;
@@ -785,6 +787,9 @@ __global__ __launch_bounds__(64) void gact_wide_kernel(const char *__restrict__ 
 typedef void (*gact_fn_t)(const char *, uint64_t, const uint32_t *, const lrm_seq_meta *, const int32_t *,
                           const char *, const uint32_t *, uint64_t, int, int, int, uint8_t *, uint64_t, int32_t *,
                           int32_t *, LrmDevCounters *);
+typedef void (*gact1_fn_t)(const char *, uint64_t, const uint32_t *, const lrm_seq_meta *, const int32_t *,
+                           const char *, const uint32_t *, uint64_t, int, int, int, uint8_t *, uint64_t, int32_t *,
+                           int32_t *, LrmDevCounters *, const uint32_t *);
 typedef void (*gact2_fn_t)(const char *, uint64_t, const uint32_t *, const lrm_seq_meta *, const int32_t *,
                            const char *, const uint32_t *, uint64_t, int, int, int, uint8_t *, uint64_t, int32_t *,
                            int32_t *, LrmDevCounters *, int);
@@ -792,7 +797,7 @@ typedef void (*gact2_fn_t)(const char *, uint64_t, const uint32_t *, const lrm_s
 static int gact_launch(lrm_gact_params gp, uint64_t n, hipStream_t stream, const char *reads, uint64_t stride,
                        const uint32_t *lens, const lrm_seq_meta *meta, const int32_t *meta_r, const char *content,
                        const uint32_t *tlens, uint8_t *store, uint64_t store_stride, int32_t *n_ops, int32_t *score,
-                       LrmDevCounters *counters) {
+                       LrmDevCounters *counters, const LrmBsArgs *bs) {
     if (gp.W > 128) {
         int dpl = gp.W <= 256 ? 2 : gp.W <= 512 ? 4 : 8;
         const int nx = 64 * dpl, padw = nx / 2 + 40;
@@ -811,12 +816,34 @@ static int gact_launch(lrm_gact_params gp, uint64_t n, hipStream_t stream, const
                            tlens, n, gp.T, gp.O, gp.W, store, store_stride, n_ops, score, counters);
         return 0;
     }
-    static int impl = -1;
-    if (impl < 0) { const char *e = getenv("LRM_GACT_IMPL"); impl = e ? atoi(e) : 3; }
+    // LRM_GACT_IMPL (read at every call so that tests can switch): 0 = automatic, 1 = one read per wavefront,
+    // 3 = packed two reads per wavefront, 4 = bit-sliced lane per read whenever it applies (W = 128, pure ACGT
+    // text, 4-byte aligned CIGAR store; otherwise as 0)
+    int impl = 0;
+    { const char *e = getenv("LRM_GACT_IMPL"); impl = e ? atoi(e) : 0; }
     static int dbg3 = -1;
     if (dbg3 < 0) { const char *e = getenv("LRM_GACT_DBG"); dbg3 = e ? atoi(e) : 0; }
     const int nblk = ((2 * (gp.T - gp.O) - 1) >> 4) + 1;
-    if (impl == 3 && nblk <= 32) {
+    // Bit-sliced kernel: a wavefront carries 64 reads, so it needs a large batch to fill the chip
+    // (below ~16 k reads the two-reads-per-wavefront kernel finishes first).
+    const bool bs_ok = bs && bs->cpl && gp.W == 128 && (((uintptr_t) store | (uintptr_t) store_stride) & 3u) == 0;
+    if (bs_ok && (impl == 4 || (impl == 0 && n >= LRM_BS_MIN_READS))) {
+        if (lrm_bs_launch(bs->qpl, bs->wpr, lens, meta, meta_r, bs->cpl, tlens, bs->flags, n, gp.T, gp.O, store,
+                          store_stride, n_ops, score, counters, stream)) return -1;
+        // reads holding a byte other than ACGT (rare): byte kernel, flagged reads only
+        GactLds L1 = gact_lds_layout(gp.T, gp.O);
+        size_t sh1 = (size_t) L1.wave_bytes * 4;
+        gact1_fn_t f1 = gact_kernel<true>;
+        if (sh1 > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(f1),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) sh1);
+            if (e != hipSuccess) { lrm_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", sh1, hipGetErrorString(e)); return -1; }
+        }
+        hipLaunchKernelGGL(f1, dim3((uint32_t) ((n + 3) / 4)), dim3(256), sh1, stream, reads, stride, lens, meta, meta_r,
+                           content, tlens, n, gp.T, gp.O, gp.W, store, store_stride, n_ops, score, counters, bs->flags);
+        return 0;
+    }
+    if (impl != 1 && nblk <= 32) {
         size_t shmem3 = (size_t) 4 * 2 * ((size_t) gp.T + 2 * G2_PAD) * 4;
         gact2_fn_t fn3;
         if (nblk <= 26) fn3 = gp.W >= 128 ? gact3_kernel<true, 26> : gact3_kernel<false, 26>;
@@ -828,7 +855,7 @@ static int gact_launch(lrm_gact_params gp, uint64_t n, hipStream_t stream, const
     }
     GactLds L = gact_lds_layout(gp.T, gp.O);
     size_t shmem = (size_t) L.wave_bytes * 4;
-    gact_fn_t fn = gp.W >= 128 ? gact_kernel<true> : gact_kernel<false>;
+    gact1_fn_t fn = gp.W >= 128 ? gact_kernel<true> : gact_kernel<false>;
     if (shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
@@ -836,7 +863,8 @@ static int gact_launch(lrm_gact_params gp, uint64_t n, hipStream_t stream, const
     }
     uint64_t blocks = (n + 3) / 4;
     hipLaunchKernelGGL(fn, dim3((uint32_t) blocks), dim3(256), shmem, stream, reads, stride, lens, meta, meta_r,
-                       content, tlens, n, gp.T, gp.O, gp.W, store, store_stride, n_ops, score, counters);
+                       content, tlens, n, gp.T, gp.O, gp.W, store, store_stride, n_ops, score, counters,
+                       (const uint32_t *) nullptr);
     return 0;
 }
 
@@ -877,9 +905,20 @@ int lrm_launch_extend(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint64_t
                            d_lens, d_meta, d_meta_r, n, cpr);
         lrm_time_end(ws, stream);
     }
-    lrm_time_begin(ws, LRM_K_GACT, stream);
+    LrmBsArgs bs = {nullptr, 0, nullptr, nullptr};
+    const bool want_bs = lrm_bs_wanted(gp, n) && idx->d_cpl && idx->cpl_ok && ws->d_qpl && n <= ws->n_max &&
+                         max_len <= ws->max_len;
+    if (want_bs) {
+        lrm_time_begin(ws, LRM_K_PACK_PLANAR, stream);
+        if (lrm_bs_pack_reads(d_reads, stride, d_lens, n, max_len, ws->d_qpl, ws->qpl_wpr, ws->d_rflags, stream)) return -1;
+        lrm_time_end(ws, stream);
+        bs.qpl = ws->d_qpl; bs.wpr = ws->qpl_wpr; bs.flags = ws->d_rflags; bs.cpl = idx->d_cpl;
+    }
+    const bool runs_bs = want_bs && (((uintptr_t) d_store | (uintptr_t) store_stride) & 3u) == 0;
+    lrm_time_begin(ws, runs_bs ? LRM_K_GACT_BS : LRM_K_GACT, stream);
     if (gact_launch(gp, n, stream, d_reads, stride, d_lens, d_meta, d_meta_r, idx->view.content,
-                    (const uint32_t *) nullptr, d_store, store_stride, d_n_ops, d_score, ws->d_counters)) return -1;
+                    (const uint32_t *) nullptr, d_store, store_stride, d_n_ops, d_score, ws->d_counters,
+                    want_bs ? &bs : nullptr)) return -1;
     lrm_time_end(ws, stream);
     HIPCHK(hipGetLastError());
     return 0;
@@ -924,7 +963,21 @@ extern "C" int lrm_debug_gact(const char *q, int n, const char *d, int m, lrm_ga
     HIPCHK(hipMemcpy(dl, hl, 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dm, &hm, sizeof(hm), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dr, hr, 12, hipMemcpyHostToDevice));
-    if (gact_launch(gp, 1, 0, dq, 0, dl, dm, dr, dd, dl + 1, dops, 0, dr + 1, dr + 2, dc)) return -1;
+    LrmBsArgs bs = {nullptr, 0, nullptr, nullptr};
+    uint64_t *dqpl = nullptr, *dcpl = nullptr;
+    uint32_t *dfl = nullptr;
+    if (lrm_bs_wanted(gp, 1)) {
+        const uint64_t wq = lrm_bs_planar_words((uint64_t) n), wd = lrm_bs_planar_words((uint64_t) m);
+        HIPCHK(hipMalloc(&dqpl, wq * 8 + 16));
+        HIPCHK(hipMalloc(&dcpl, wd * 8 + 16));
+        HIPCHK(hipMalloc(&dfl, 16));
+        if (lrm_bs_pack_text(dd, (uint64_t) m, dcpl, dfl + 1, nullptr)) return -1;
+        if (lrm_bs_pack_reads(dq, 0, dl, 1, (uint32_t) n, dqpl, wq, dfl, nullptr)) return -1;
+        uint32_t tf = 0;
+        HIPCHK(hipMemcpy(&tf, dfl + 1, 4, hipMemcpyDeviceToHost));
+        bs.qpl = dqpl; bs.wpr = wq; bs.flags = dfl; bs.cpl = tf ? nullptr : dcpl;
+    }
+    if (gact_launch(gp, 1, 0, dq, 0, dl, dm, dr, dd, dl + 1, dops, 0, dr + 1, dr + 2, dc, bs.qpl ? &bs : nullptr)) return -1;
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(hr, dr, 12, hipMemcpyDeviceToHost));
@@ -933,5 +986,8 @@ extern "C" int lrm_debug_gact(const char *q, int n, const char *d, int m, lrm_ga
     if (hr[1] > 0) HIPCHK(hipMemcpy(ops, dops, (size_t) hr[1], hipMemcpyDeviceToHost));
     (void) hipFree(dq); (void) hipFree(dd); (void) hipFree(dops); (void) hipFree(dl);
     (void) hipFree(dm); (void) hipFree(dr); (void) hipFree(dc);
+    if (dqpl) (void) hipFree(dqpl);
+    if (dcpl) (void) hipFree(dcpl);
+    if (dfl) (void) hipFree(dfl);
     return 0;
 }

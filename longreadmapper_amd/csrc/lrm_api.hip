@@ -197,6 +197,7 @@ static int make_handle(lrm_index **out, void *d_blob, uint64_t bytes, int device
     ix->view.sa_len = h.sa_len; ix->view.con_len = h.con_len;
     for (int i = 0; i < 4; ++i) ix->view.c4[i] = h.c4[i];
     ix->view.hlen = h.hlen; ix->view.mta_len = h.mta_len;
+    if (lrm_bs_prepare_index(ix)) { delete ix; return -1; }
     *out = ix;
     return 0;
 }
@@ -252,7 +253,9 @@ static thread_local HostCache g_cache = {nullptr};
 extern "C" void lrm_index_free(lrm_index *idx) {
     if (!idx) return;
     if (g_cache.ws && g_cache.ws->idx == idx) { lrm_workspace_free(g_cache.ws); g_cache.ws = nullptr; }
-    if (idx->owns_blob && idx->d_blob) { (void) hipSetDevice(idx->device); (void) hipFree(idx->d_blob); }
+    (void) hipSetDevice(idx->device);
+    lrm_bs_free_index(idx);
+    if (idx->owns_blob && idx->d_blob) (void) hipFree(idx->d_blob);
     delete idx;
 }
 
@@ -264,6 +267,7 @@ extern "C" void lrm_workspace_free(lrm_workspace *ws) {
     (void) hipSetDevice(ws->device);
     (void) hipFree(ws->d_reads2); (void) hipFree(ws->d_rec); (void) hipFree(ws->d_phase); (void) hipFree(ws->d_decided);
     (void) hipFree(ws->d_hcount); (void) hipFree(ws->d_counters);
+    (void) hipFree(ws->d_qpl); (void) hipFree(ws->d_rflags);
     for (int i = 0; i < LRM_MAX_TIMED; ++i) {
         if (ws->ev_start[i]) (void) hipEventDestroy((hipEvent_t) ws->ev_start[i]);
         if (ws->ev_stop[i]) (void) hipEventDestroy((hipEvent_t) ws->ev_stop[i]);
@@ -290,6 +294,7 @@ extern "C" int lrm_workspace_create(lrm_workspace **out, lrm_index *idx, uint64_
     ws->cap_q = (jl + ws->P - 1) / ws->P;
     if (ws->cap_q == 0) ws->cap_q = 1;
     ws->words_per_read = (uint64_t) max_len / 32 + 2;
+    ws->qpl_wpr = lrm_bs_planar_words(max_len);
     struct { void **p; uint64_t bytes; } allocs[] = {
         {(void **) &ws->d_reads2, n_max * ws->words_per_read * 8},
         {(void **) &ws->d_rec, n_max * (uint64_t) ws->P * ws->cap_q * 8},
@@ -297,6 +302,8 @@ extern "C" int lrm_workspace_create(lrm_workspace **out, lrm_index *idx, uint64_
         {(void **) &ws->d_decided, n_max},
         {(void **) &ws->d_hcount, n_max * (uint64_t) ws->P * 4},
         {(void **) &ws->d_counters, sizeof(LrmDevCounters)},
+        {(void **) &ws->d_qpl, n_max * ws->qpl_wpr * 8 + 16},
+        {(void **) &ws->d_rflags, n_max * 4},
     };
     for (auto &a : allocs) {
         if (hipMalloc(a.p, a.bytes) != hipSuccess) {
@@ -411,7 +418,8 @@ extern "C" int lrm_workspace_timing(lrm_workspace *ws, double *ms, uint64_t *lau
 extern "C" const char *lrm_kernel_name(int k) {
     static const char *names[LRM_K_COUNT] = {"pack2bit_kernel", "seed_search_kernel", "vote_wave_kernel",
                                              "vote_wave2_kernel", "decide_kernel", "locus_resolve_kernel",
-                                             "revcomp_kernel", "gact_kernel", "vote_block_kernel"};
+                                             "revcomp_kernel", "gact_kernel", "vote_block_kernel",
+                                             "bs_pack_reads_kernel", "gact_bs_kernel"};
     return k >= 0 && k < LRM_K_COUNT ? names[k] : "?";
 }
 
@@ -480,20 +488,21 @@ extern "C" int lrm_extend_batch(lrm_index *idx, char *reads_buf, uint64_t stride
     if (!ws || ws->idx != idx) {
         if (get_cached_ws(idx, n, max_len, 20, 300, &ws)) return -1;   // extend only needs the counters block
     }
+    const uint64_t dstride = (store_stride + 3) & ~3ull;     // the bit-sliced kernel stores CIGAR bytes four at a time
     DevBuf d_reads, d_lens, d_best, d_store, d_nops, d_score, d_meta, d_mr;
     if (d_reads.alloc(n * stride) || d_lens.alloc(n * 4) || d_best.alloc(n * sizeof(lrm_entry)) ||
-        d_store.alloc(n * store_stride) || d_nops.alloc(n * 4) || d_score.alloc(n * 4) ||
+        d_store.alloc(n * dstride) || d_nops.alloc(n * 4) || d_score.alloc(n * 4) ||
         d_meta.alloc(n * sizeof(lrm_seq_meta)) || d_mr.alloc(n * 4)) { lrm_set_error("device allocation failed"); return -1; }
     HIPCHK(hipMemcpy(d_reads.p, reads_buf, n * stride, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_lens.p, lens, n * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_best.p, best, n * sizeof(lrm_entry), hipMemcpyHostToDevice));
     if (lrm_launch_extend(idx, ws, (char *) d_reads.p, stride, (const uint32_t *) d_lens.p, n, max_len,
-                          (const lrm_entry *) d_best.p, gp, (uint8_t *) d_store.p, store_stride, (int32_t *) d_nops.p,
+                          (const lrm_entry *) d_best.p, gp, (uint8_t *) d_store.p, dstride, (int32_t *) d_nops.p,
                           (int32_t *) d_score.p, (lrm_seq_meta *) d_meta.p, (int32_t *) d_mr.p, nullptr)) return -1;
     HIPCHK(hipDeviceSynchronize());
     std::vector<int32_t> nops(n);
     HIPCHK(hipMemcpy(reads_buf, d_reads.p, n * stride, hipMemcpyDeviceToHost));      // rev-comped reads travel back
-    HIPCHK(hipMemcpy(store_mem, d_store.p, n * store_stride, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy2D(store_mem, store_stride, d_store.p, dstride, store_stride, n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(nops.data(), d_nops.p, n * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(score_out, d_score.p, n * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(meta_out, d_meta.p, n * sizeof(lrm_seq_meta), hipMemcpyDeviceToHost));

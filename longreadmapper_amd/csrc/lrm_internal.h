@@ -83,6 +83,8 @@ struct lrm_index {
     int device;
     LrmBlobHeader hdr;
     LrmIndexView view;
+    uint64_t *d_cpl;          // planar 2-bit copy of the text for the bit-sliced GACT kernel (owned; may be null)
+    int cpl_ok;               // text is pure ACGT (otherwise the byte kernels are used)
 };
 
 // Per-(read,phase) vote result written by the vote kernels.
@@ -101,7 +103,8 @@ struct LrmDevCounters {
 };
 
 enum LrmKernelId { LRM_K_PACK2BIT = 0, LRM_K_SEED_SEARCH, LRM_K_VOTE, LRM_K_VOTE_FALLBACK, LRM_K_DECIDE,
-                   LRM_K_LOCUS, LRM_K_REVCOMP, LRM_K_GACT, LRM_K_VOTE_BLOCK, LRM_K_COUNT };
+                   LRM_K_LOCUS, LRM_K_REVCOMP, LRM_K_GACT, LRM_K_VOTE_BLOCK, LRM_K_PACK_PLANAR, LRM_K_GACT_BS,
+                   LRM_K_COUNT };
 #define LRM_MAX_TIMED 4096
 
 struct lrm_workspace {
@@ -126,7 +129,26 @@ struct lrm_workspace {
     uint8_t *d_decided;      // n_max
     uint32_t *d_hcount;      // hits per (read, phase): routes an item to its vote-table tier
     LrmDevCounters *d_counters;
+    // bit-sliced GACT: planar reads (wpr words per read) and per-read "byte other than ACGT" flags
+    uint64_t *d_qpl;
+    uint64_t qpl_wpr;
+    uint32_t *d_rflags;
 };
+
+#define LRM_BS_PADW 24       // planar words of padding on either side of a packed sequence
+#define LRM_BS_MIN_READS 16384
+struct LrmBsArgs { const uint64_t *qpl; uint64_t wpr; const uint32_t *flags; const uint64_t *cpl; };
+uint64_t lrm_bs_planar_words(uint64_t len);
+bool lrm_bs_wanted(lrm_gact_params gp, uint64_t n);      // W = 128 and (LRM_GACT_IMPL=4 or automatic with a large batch)
+int lrm_bs_pack_reads(const char *d_reads, uint64_t stride, const uint32_t *d_lens, uint64_t n, uint32_t max_len,
+                      uint64_t *d_qpl, uint64_t wpr, uint32_t *d_flags, void *stream);
+int lrm_bs_pack_text(const char *d_text, uint64_t len, uint64_t *d_out, uint32_t *d_flag, void *stream);
+int lrm_bs_launch(const uint64_t *d_qpl, uint64_t wpr, const uint32_t *d_lens, const lrm_seq_meta *d_meta,
+                  const int32_t *d_meta_r, const uint64_t *d_cpl, const uint32_t *d_tlens, const uint32_t *d_flags,
+                  uint64_t n, int T, int O, uint8_t *d_store, uint64_t store_stride, int32_t *d_n_ops,
+                  int32_t *d_score, LrmDevCounters *counters, void *stream);
+int lrm_bs_prepare_index(lrm_index *idx);
+void lrm_bs_free_index(lrm_index *idx);
 
 void lrm_set_error(const char *fmt, ...);
 void lrm_time_begin(lrm_workspace *ws, int kernel, void *stream);

@@ -17,6 +17,7 @@ assert ENTRY_DT.itemsize == 24 and META_DT.itemsize == 24
 DEFAULT_SEED_LEN = 20      # alnmain.c:577-580
 DEFAULT_THRES = 300
 DEFAULT_GACT = (320, 120, 128)
+N_KERNELS = 11             # LRM_N_KERNELS in include/lrm_accel.h
 
 
 def seed_batch(index, reads, lens, seed_len=DEFAULT_SEED_LEN, thres=DEFAULT_THRES):
@@ -124,11 +125,11 @@ class DeviceMapper:
 
     def timing(self):
         """-> {kernel name: (total ms, launches)} accumulated since set_timing / the last call."""
-        ms = np.zeros(9, dtype=np.float64)
-        launches = np.zeros(9, dtype=np.uint64)
+        ms = np.zeros(N_KERNELS, dtype=np.float64)
+        launches = np.zeros(N_KERNELS, dtype=np.uint64)
         check(lib.lrm_workspace_timing(self.ws, ms.ctypes.data, launches.ctypes.data, self._stream()),
               "lrm_workspace_timing")
-        return {lib.lrm_kernel_name(i).decode(): (float(ms[i]), int(launches[i])) for i in range(9)}
+        return {lib.lrm_kernel_name(i).decode(): (float(ms[i]), int(launches[i])) for i in range(N_KERNELS)}
 
     def results(self, n):
         """Copy the outputs of the last seed+extend to numpy (host)."""

@@ -1,0 +1,222 @@
+/*
+ * CPU model of the bit-sliced GACT kernel (longreadmapper_amd/csrc/gact_bs_kernel.hip), one "lane".
+ * TEST INFRASTRUCTURE: the model exists so that the kernel's formulation -- difference encoding,
+ * 64 cells per machine word, streamed sequence planes, checkpoint + recompute traceback -- can be
+ * checked against oracle/lrm_oracle.c:orc_gact on the CPU, statement by statement.  The HIP kernel runs
+ * this exact sequence of operations per lane.
+ *
+ * Formulation (docs/GACT_SPEC.md, "Tile DP"):
+ *   V(a,b) = R[a][b] - R[a+1][b],  H(a,b) = R[a][b] - R[a][b+1]   both in [-1, 2]  -> 2-bit code value+1
+ *   cell (a,b), u = H(a+1,b), w = V(a,b+1), s = +1/-1:
+ *       X = R[a][b] - R[a+1][b+1] = max(s, u-1, w-1);  V(a,b) = X - u;  H(a,b) = X - w
+ *       DIAG iff s >= u-1 and s >= w-1;  else INS iff u >= w;  else DEL
+ *   band W = 128: anti-diagonal s holds 64 cells t = 0..63, diagonal d = 2t - 64 (+1 when s is odd),
+ *       a = A0 - t, b = B0 + t with A0 = (s + 64 - (s&1)) >> 1, B0 = s - A0.
+ *   neighbours: even s: u = H_prev << 1, w = V_prev;  odd s: u = H_prev, w = V_prev >> 1 (zeros shifted
+ *       in = code 0 = "never wins" = the out-of-band -inf).
+ *   boundary cells (a == tq or b == tt) are forced to V = H = 0 (code 1).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define BS_K 32                 /* anti-diagonals per traceback block */
+#define BS_PAD 8                /* planar words of padding on either side of a sequence */
+
+typedef struct { uint32_t lo, hi; } bs_word;      /* 32 bases: bit k of lo/hi = low/high code bit of base k */
+
+static int bs_code(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+
+/* planar packing; returns pointer to word 0 (BS_PAD zero words precede and follow) or NULL if non-ACGT */
+static bs_word *bs_pack(const char *x, int len, bs_word **base_out) {
+    int nw = (len + 31) / 32 + 2 * BS_PAD + 1;
+    bs_word *base = (bs_word *) calloc((size_t) nw, sizeof(bs_word));
+    bs_word *w = base + BS_PAD;
+    for (int k = 0; k < len; ++k) {
+        int c = bs_code(x[k]);
+        if (c < 0) { free(base); return NULL; }
+        w[k >> 5].lo |= (uint32_t) (c & 1) << (k & 31);
+        w[k >> 5].hi |= (uint32_t) (c >> 1) << (k & 31);
+    }
+    *base_out = base;
+    return w;
+}
+
+static uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {         /* v_alignbit_b32 */
+    sh &= 31;
+    return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+}
+static uint32_t brev32(uint32_t x) {                                      /* v_bfrev_b32 */
+    uint32_t r = 0;
+    for (int i = 0; i < 32; ++i) r |= ((x >> i) & 1u) << (31 - i);
+    return r;
+}
+/* 32 bases starting at position pos (may be negative or past the end: padding / neighbouring data) */
+static bs_word fetch32(const bs_word *pl, long pos) {
+    long k = pos >> 5;
+    uint32_t sh = (uint32_t) (pos & 31);
+    bs_word r;
+    r.lo = alignbit(pl[k + 1].lo, pl[k].lo, sh);
+    r.hi = alignbit(pl[k + 1].hi, pl[k].hi, sh);
+    return r;
+}
+static uint32_t onehot32(long x) { return (x >= 0 && x < 32) ? (1u << x) : 0u; }
+
+typedef struct {
+    /* stream windows: 3 words per plane; plane index 0 = lo, 1 = hi, 2 = sentinel */
+    uint32_t qw[3][3], dw[3][3];
+    int shq, shd;               /* window offsets: Q = (qw >> shq), D = (dw >> shd) */
+    long qnext;                 /* a of bit 0 of the next Q stream word (descending stream) */
+    long dnext;                 /* b of bit 0 of the next (lower) D word */
+    uint64_t Q[3], D[3];
+} bs_stream;
+
+typedef struct {
+    const bs_word *qpl, *dpl;
+    long i, j;                  /* anchor */
+    int tq, tt;
+} bs_tile;
+
+static void q_word(const bs_tile *t, long a_hi, uint32_t out[3]) {
+    /* stream word whose bit b holds a = a_hi - b */
+    bs_word f = fetch32(t->qpl, t->i + a_hi - 31);
+    out[0] = brev32(f.lo);
+    out[1] = brev32(f.hi);
+    out[2] = onehot32(a_hi - t->tq);
+}
+static void d_word(const bs_tile *t, long b_lo, uint32_t out[3]) {
+    /* word whose bit b holds target position b_lo + b */
+    bs_word f = fetch32(t->dpl, t->j + b_lo);
+    out[0] = f.lo;
+    out[1] = f.hi;
+    out[2] = onehot32(t->tt - b_lo);
+}
+static void extract(bs_stream *st) {
+    for (int p = 0; p < 3; ++p) {
+        st->Q[p] = (uint64_t) alignbit(st->qw[p][1], st->qw[p][0], (uint32_t) st->shq) |
+                   ((uint64_t) alignbit(st->qw[p][2], st->qw[p][1], (uint32_t) st->shq) << 32);
+        st->D[p] = (uint64_t) alignbit(st->dw[p][1], st->dw[p][0], (uint32_t) st->shd) |
+                   ((uint64_t) alignbit(st->dw[p][2], st->dw[p][1], (uint32_t) st->shd) << 32);
+    }
+}
+/* windows for anti-diagonal s; room for `room_q` Q transitions and `room_d` D transitions without refill
+ * when room <= 31 (shq starts at 0, shd at room_d) */
+static void stream_init(bs_stream *st, const bs_tile *t, int s, int room_d) {
+    const int par = s & 1;
+    const long A0 = (s + 64 - par) >> 1, B0 = s - A0;
+    uint32_t w[3];
+    for (int k = 0; k < 3; ++k) {
+        q_word(t, A0 - 32 * k, w);
+        for (int p = 0; p < 3; ++p) st->qw[p][k] = w[p];
+        d_word(t, B0 - room_d + 32 * k, w);
+        for (int p = 0; p < 3; ++p) st->dw[p][k] = w[p];
+    }
+    st->shq = 0;
+    st->shd = room_d;
+    st->qnext = A0 - 96;
+    st->dnext = B0 - room_d - 32;
+    extract(st);
+}
+static void q_transition(bs_stream *st, const bs_tile *t) {            /* after an even anti-diagonal */
+    if (++st->shq == 32) {
+        uint32_t w[3];
+        q_word(t, st->qnext, w);
+        for (int p = 0; p < 3; ++p) { st->qw[p][0] = st->qw[p][1]; st->qw[p][1] = st->qw[p][2]; st->qw[p][2] = w[p]; }
+        st->qnext -= 32;
+        st->shq = 0;
+    }
+    extract(st);
+}
+static void d_transition(bs_stream *st, const bs_tile *t) {            /* after an odd anti-diagonal */
+    if (--st->shd < 0) {
+        uint32_t w[3];
+        d_word(t, st->dnext, w);
+        for (int p = 0; p < 3; ++p) { st->dw[p][2] = st->dw[p][1]; st->dw[p][1] = st->dw[p][0]; st->dw[p][0] = w[p]; }
+        st->dnext -= 32;
+        st->shd = 31;
+    }
+    extract(st);
+}
+
+typedef struct { uint64_t V1, V0, H1, H0; } bs_state;
+
+/* one anti-diagonal; N/G: traceback planes (N = not diagonal; G = deletion if N else mismatch) */
+static void bs_step(bs_state *x, const bs_stream *st, int odd, uint64_t *Nout, uint64_t *Gout) {
+    uint64_t u1, u0, w1, w0;
+    if (!odd) { u1 = x->H1 << 1; u0 = x->H0 << 1; w1 = x->V1; w0 = x->V0; }
+    else      { u1 = x->H1; u0 = x->H0; w1 = x->V1 >> 1; w0 = x->V0 >> 1; }
+    const uint64_t m = ~((st->Q[0] ^ st->D[0]) | (st->Q[1] ^ st->D[1]));
+    const uint64_t d0 = u0 ^ w0, b0 = ~u0 & w0, t1 = u1 ^ w1, d1 = t1 ^ b0;
+    const uint64_t lt = (~u1 & w1) | (~t1 & b0);
+    const uint64_t big = u1 | w1, nd = ~m & big, del = nd & lt, ins = nd & ~lt, n1 = d1 ^ d0;
+    uint64_t V1 = (m & ~u1) | (del & n1), V0 = (~nd & ~u0) | (del & d0);
+    uint64_t H1 = (m & ~w1) | (ins & d1), H0 = (~nd & ~w0) | (ins & d0);
+    const uint64_t Bm = st->Q[2] | st->D[2];
+    x->V1 = V1 & ~Bm; x->V0 = V0 | Bm; x->H1 = H1 & ~Bm; x->H0 = H0 | Bm;
+    if (Nout) { *Nout = nd; *Gout = del | ~(m | big); }
+}
+
+/* returns the score (X + I + D) or -1 (non-ACGT input: the kernel routes such reads to the byte kernels) */
+int bsm_gact(const char *q, int n, const char *d, int m, int T, int O, int extra_s0,
+             uint8_t *ops, int *n_ops) {
+    *n_ops = 0;
+    bs_word *qb, *db;
+    bs_word *qpl = bs_pack(q, n, &qb);
+    if (!qpl) return -1;
+    bs_word *dpl = bs_pack(d, m, &db);
+    if (!dpl) { free(qb); return -1; }
+    const int cap = T - O, lim2 = 2 * cap;
+    const int nblk = (lim2 + BS_K - 1) / BS_K;
+    bs_state *ckpt = (bs_state *) malloc(sizeof(bs_state) * (size_t) (nblk + 2));
+    long i = 0, j = 0;
+    int nops = 0, score = 0;
+    while (i < n && j < m) {
+        bs_tile t = { qpl, dpl, i, j, (n - i) < T ? (int) (n - i) : T, (m - j) < T ? (int) (m - j) : T };
+        const int last = (i + t.tq == n);
+        const int S0 = ((t.tq + t.tt + BS_K - 1) / BS_K) * BS_K + extra_s0;
+        const int nb = nblk < S0 / BS_K ? nblk : S0 / BS_K;
+        bs_state x = { 0, ~0ull, 0, ~0ull };
+        bs_stream st;
+        /* pass 1: scores only, checkpoints at the block boundaries */
+        stream_init(&st, &t, S0, 31);
+        for (int s = S0; s >= BS_K; s -= 2) {
+            bs_step(&x, &st, 0, NULL, NULL);
+            if (s % BS_K == 0 && s / BS_K <= nb) ckpt[s / BS_K] = x;
+            if (s == BS_K) break;
+            q_transition(&st, &t);
+            bs_step(&x, &st, 1, NULL, NULL);
+            d_transition(&st, &t);
+        }
+        /* pass 2: per block recompute with traceback planes, then walk through the block */
+        int a = 0, b = 0, running = 1;
+        for (int c = 0; c < nb && running; ++c) {
+            uint64_t N[BS_K], G[BS_K];
+            x = ckpt[c + 1];
+            stream_init(&st, &t, BS_K * c + BS_K - 1, 16);
+            for (int k = BS_K - 1; k >= 1; k -= 2) {
+                bs_step(&x, &st, 1, &N[k], &G[k]);
+                d_transition(&st, &t);
+                bs_step(&x, &st, 0, &N[k - 1], &G[k - 1]);
+                if (k > 1) q_transition(&st, &t);
+            }
+            for (int k = 0; k < BS_K; ++k) {
+                const int act = running && (a + b == BS_K * c + k);
+                if (!act) continue;
+                const int tpos = (b - a + 64) >> 1;
+                const int nbit = (int) ((N[k] >> tpos) & 1), gbit = (int) ((G[k] >> tpos) & 1);
+                ops[nops++] = "=XID"[nbit * 2 + gbit];
+                score += nbit | gbit;
+                a += !(nbit && gbit);
+                b += !(nbit && !gbit);
+                running = a < t.tq && b < t.tt && (last ? (a + b < lim2) : (a < cap && b < cap));
+            }
+        }
+        i += a;
+        j += b;
+        if (a + b == 0) { score = -1; break; }
+    }
+    if (score >= 0) while (i < n) { ops[nops++] = 'I'; score++; i++; }
+    free(ckpt); free(qb); free(db);
+    *n_ops = nops;
+    return score;
+}

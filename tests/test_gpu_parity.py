@@ -76,6 +76,38 @@ def test_gact_kernel_vs_oracle(gpu, T, O, W):
     assert _gpu_gact(q, d, T, O, W) == orc.gact(q, d, T, O, W)[:2]
 
 
+BS_PARAMS = [(320, 120, 128), (512, 120, 128), (100, 99, 128), (320, 0, 128), (64, 16, 128), (33, 7, 128), (16, 0, 128),
+             (512, 0, 128)]
+
+
+@pytest.mark.parametrize("T,O,W", BS_PARAMS)
+def test_gact_bitsliced_kernel_vs_oracle(gpu, monkeypatch, T, O, W):
+    """LRM_GACT_IMPL=4: the lane-per-read bit-sliced kernel (normally used for batches >= 16 k reads)."""
+    monkeypatch.setenv("LRM_GACT_IMPL", "4")
+    rng = np.random.default_rng(T * 1000 + O * 10 + 7)
+    ref = bytes(synth.reference(20000, seed=3))
+    sizes = [1, 2, 5, 31, 63, 64, 65, 127, 199, 200, 201, 319, 320, 321, 500, 1000, 2500]
+    for n in sizes:
+        for prof in ((0, 0, 0), (0.04, 0.03, 0.03), (0.015, 0.09, 0.045), (0.2, 0.1, 0.1)):
+            p = int(rng.integers(0, len(ref) - 3 * n - 64))
+            q = _mutate(rng, ref[p:p + n], *prof) or b"C"
+            for m in {len(q), max(1, len(q) - 7), len(q) + 13}:
+                d = ref[p:p + m]
+                want = orc.gact(q, d, T, O, W)
+                got = _gpu_gact(q, d, T, O, W)
+                assert got == (want[0], want[1]), (n, prof, m)
+    q, d = ref[100:700], ref[9000:9600]
+    assert _gpu_gact(q, d, T, O, W) == orc.gact(q, d, T, O, W)[:2]
+    q, d = ref[140:900], ref[100:860]
+    assert _gpu_gact(q, d, T, O, W) == orc.gact(q, d, T, O, W)[:2]
+    # a byte other than ACGT in the read or in the text: routed to the byte kernel, same answer
+    q, d = bytearray(ref[300:1300]), bytearray(ref[300:1300])
+    q[500] = ord("N")
+    assert _gpu_gact(bytes(q), bytes(d), T, O, W) == orc.gact(bytes(q), bytes(d), T, O, W)[:2]
+    d[100] = ord("a")
+    assert _gpu_gact(bytes(q), bytes(d), T, O, W) == orc.gact(bytes(q), bytes(d), T, O, W)[:2]
+
+
 def test_gact_rejects_unsupported_params(gpu):
     q = np.frombuffer(b"ACGT", dtype=np.uint8)
     ops = np.zeros(16, dtype=np.uint8)
@@ -147,8 +179,11 @@ def test_vote_tiers_beyond_the_wave_table(dev_indexes, gpu):
 
 
 @pytest.mark.parametrize("name", ["clean-1k", "ont-2k", "pacbio-3k-h12", "ragged", "repeats-ties"])
-@pytest.mark.parametrize("gact", [(320, 120, 128), (128, 64, 32)])
-def test_extend_batch_vs_oracle(dev_indexes, name, gact):
+@pytest.mark.parametrize("gact", [(320, 120, 128), (128, 64, 32), (320, 120, 128, "bitsliced")])
+def test_extend_batch_vs_oracle(dev_indexes, monkeypatch, name, gact):
+    if len(gact) == 4:
+        monkeypatch.setenv("LRM_GACT_IMPL", "4")
+        gact = gact[:3]
     sc, di, oi = dev_indexes(name)
     best, _ = oi.seed_batch(sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
     if name == "ragged":     # also: a wrapped diagonal, a locus straddling the strand boundary, the last bases
@@ -197,6 +232,39 @@ def test_device_resident_pipeline_equals_host_path(dev_indexes, gpu):
     assert np.array_equal(d_reads.cpu().numpy(), r)
     st = dm.stats()
     assert st["gact_tiles"] > 0
+    dm.close()
+
+
+@pytest.mark.parametrize("name", ["ont-2k", "ragged"])
+def test_bitsliced_kernel_is_the_one_that_runs(dev_indexes, gpu, monkeypatch, name):
+    """Device-resident extend with LRM_GACT_IMPL=4: the launch record must show gact_bs_kernel (no silent
+    route through the byte kernels), results equal the oracle's; one read carries an N (byte kernel, flagged)."""
+    import torch
+    monkeypatch.setenv("LRM_GACT_IMPL", "4")
+    sc, di, oi = dev_indexes(name)
+    reads = sc["reads"].copy()
+    if name == "ont-2k":
+        reads[3, 700] = ord("N")
+    n, stride = reads.shape
+    dm = mapper.DeviceMapper(di, n, stride - 1, sc["seed_len"], sc["thres"], device=gpu)
+    dm.set_timing(True)
+    d_reads = torch.from_numpy(reads.copy()).cuda()
+    d_lens = torch.from_numpy(sc["lens"].astype(np.int32)).cuda()
+    dm.seed(d_reads, d_lens)
+    dm.extend(d_reads, d_lens)
+    torch.cuda.synchronize()
+    t = dm.timing()
+    assert t["gact_bs_kernel"][1] == 1 and t["bs_pack_reads_kernel"][1] == 1 and t["gact_kernel"][1] == 0
+    res = dm.results(n)
+    best, _ = oi.seed_batch(reads, sc["lens"], sc["seed_len"], sc["thres"])
+    assert np.array_equal(res["best"], best)
+    r_cpu = reads.copy()
+    want = oi.extend_batch(r_cpu, sc["lens"], best, (320, 120, 128))
+    assert np.array_equal(res["score"], want["score"]) and np.array_equal(res["n_ops"], want["n_ops"])
+    for i in range(n):
+        k = int(want["n_ops"][i])
+        assert bytes(res["ops"][i, :k]) == bytes(want["ops"][i, :k]), i
+    assert np.array_equal(d_reads.cpu().numpy(), r_cpu)
     dm.close()
 
 
