@@ -34,7 +34,8 @@
 #include <cstdlib>
 #include "lrm_internal.h"
 
-#define BS_K 32
+#define BS_K 16                 // anti-diagonals per traceback block (even, <= 32)
+#define BS_H (BS_K / 2)
 #define BS_PADW LRM_BS_PADW
 
 struct __attribute__((aligned(8))) BsPair { uint64_t a, b; };
@@ -108,51 +109,57 @@ struct BsTile {
 
 struct BsWord { uint32_t lo, hi, sent; };
 
-// stream word whose bit b holds read base a_hi - b (the read runs backwards through the planes)
-__device__ __forceinline__ BsWord bs_q_word(const BsTile &t, int a_hi) {
-    const int pos = t.i + a_hi - 31;
-    const int k = pos >> 5;
-    const uint32_t sh = (uint32_t) pos & 31u;
+// stream word whose bit b holds read base a_hi - b (the read runs backwards through the planes):
+// a 16-byte gather of two adjacent planar words, then a funnel shift by the lane's own alignment
+__device__ __forceinline__ BsPair bs_q_raw(const BsTile &t, int a_hi) {
     BsPair p;
-    __builtin_memcpy(&p, t.qpl + k, sizeof(p));
+    __builtin_memcpy(&p, t.qpl + ((t.i + a_hi - 31) >> 5), sizeof(p));
+    return p;
+}
+__device__ __forceinline__ BsWord bs_q_conv(const BsTile &t, int a_hi, const BsPair &p) {
+    const uint32_t sh = (uint32_t) (t.i + a_hi - 31) & 31u;
     BsWord w;
     w.lo = __builtin_bitreverse32(bs_alignbit((uint32_t) p.b, (uint32_t) p.a, sh));
     w.hi = __builtin_bitreverse32(bs_alignbit((uint32_t) (p.b >> 32), (uint32_t) (p.a >> 32), sh));
     w.sent = bs_onehot(a_hi - t.tq);
     return w;
 }
+__device__ __forceinline__ BsWord bs_q_word(const BsTile &t, int a_hi) { return bs_q_conv(t, a_hi, bs_q_raw(t, a_hi)); }
 // word whose bit b holds text base b_lo + b
-__device__ __forceinline__ BsWord bs_d_word(const BsTile &t, int b_lo) {
-    const int64_t pos = t.dpos + b_lo;
-    const int64_t k = pos >> 5;
-    const uint32_t sh = (uint32_t) pos & 31u;
+__device__ __forceinline__ BsPair bs_d_raw(const BsTile &t, int b_lo) {
     BsPair p;
-    __builtin_memcpy(&p, t.dpl + k, sizeof(p));
+    __builtin_memcpy(&p, t.dpl + ((t.dpos + b_lo) >> 5), sizeof(p));
+    return p;
+}
+__device__ __forceinline__ BsWord bs_d_conv(const BsTile &t, int b_lo, const BsPair &p) {
+    const uint32_t sh = (uint32_t) (t.dpos + b_lo) & 31u;
     BsWord w;
     w.lo = bs_alignbit((uint32_t) p.b, (uint32_t) p.a, sh);
     w.hi = bs_alignbit((uint32_t) (p.b >> 32), (uint32_t) (p.a >> 32), sh);
     w.sent = bs_onehot(t.tt - b_lo);
     return w;
 }
+__device__ __forceinline__ BsWord bs_d_word(const BsTile &t, int b_lo) { return bs_d_conv(t, b_lo, bs_d_raw(t, b_lo)); }
+
+struct BsPl { uint32_t lo, hi; };                    // one bit-plane of an anti-diagonal: 64 lattice points
 
 struct BsStream {
     BsWord q0, q1, q2, d0, d1, d2;     // three consecutive stream words each
-    uint64_t Qlo, Qhi, Qs, Dlo, Dhi, Ds;
+    BsPl Qlo, Qhi, Qs, Dlo, Dhi, Ds;
     int qnext, dnext;                  // wave-uniform: a of bit 0 of the next query word / b of the next (lower) text word
 };
 
-__device__ __forceinline__ uint64_t bs_win(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t sh) {
-    return (uint64_t) bs_alignbit(w1, w0, sh) | ((uint64_t) bs_alignbit(w2, w1, sh) << 32);
-}
+template <bool BOUND>
 __device__ __forceinline__ void bs_extract_q(BsStream &st, uint32_t shq) {
-    st.Qlo = bs_win(st.q0.lo, st.q1.lo, st.q2.lo, shq);
-    st.Qhi = bs_win(st.q0.hi, st.q1.hi, st.q2.hi, shq);
-    st.Qs = bs_win(st.q0.sent, st.q1.sent, st.q2.sent, shq);
+    st.Qlo.lo = bs_alignbit(st.q1.lo, st.q0.lo, shq);  st.Qlo.hi = bs_alignbit(st.q2.lo, st.q1.lo, shq);
+    st.Qhi.lo = bs_alignbit(st.q1.hi, st.q0.hi, shq);  st.Qhi.hi = bs_alignbit(st.q2.hi, st.q1.hi, shq);
+    if (BOUND) { st.Qs.lo = bs_alignbit(st.q1.sent, st.q0.sent, shq); st.Qs.hi = bs_alignbit(st.q2.sent, st.q1.sent, shq); }
 }
+template <bool BOUND>
 __device__ __forceinline__ void bs_extract_d(BsStream &st, uint32_t shd) {
-    st.Dlo = bs_win(st.d0.lo, st.d1.lo, st.d2.lo, shd);
-    st.Dhi = bs_win(st.d0.hi, st.d1.hi, st.d2.hi, shd);
-    st.Ds = bs_win(st.d0.sent, st.d1.sent, st.d2.sent, shd);
+    st.Dlo.lo = bs_alignbit(st.d1.lo, st.d0.lo, shd);  st.Dlo.hi = bs_alignbit(st.d2.lo, st.d1.lo, shd);
+    st.Dhi.lo = bs_alignbit(st.d1.hi, st.d0.hi, shd);  st.Dhi.hi = bs_alignbit(st.d2.hi, st.d1.hi, shd);
+    if (BOUND) { st.Ds.lo = bs_alignbit(st.d1.sent, st.d0.sent, shd); st.Ds.hi = bs_alignbit(st.d2.sent, st.d1.sent, shd); }
 }
 // windows for anti-diagonal s; the text window starts room_d bases into its words
 __device__ __forceinline__ void bs_stream_init(BsStream &st, const BsTile &t, int s, int room_d) {
@@ -165,27 +172,68 @@ __device__ __forceinline__ void bs_stream_init(BsStream &st, const BsTile &t, in
     st.d2 = bs_d_word(t, B0 - room_d + 64);
     st.qnext = A0 - 96;
     st.dnext = B0 - room_d - 32;
-    bs_extract_q(st, 0);
-    bs_extract_d(st, (uint32_t) room_d);
+    bs_extract_q<true>(st, 0);
+    bs_extract_d<true>(st, (uint32_t) room_d);
+}
+// does any lane hold a free-exit point in its current stream words?  (wave-uniform)
+__device__ __forceinline__ bool bs_any_sentinel(const BsStream &st) {
+    return __ballot((st.q0.sent | st.q1.sent | st.q2.sent | st.d0.sent | st.d1.sent | st.d2.sent) != 0u) != 0ull;
 }
 
-struct BsState { uint64_t V1, V0, H1, H0; };
+struct BsState { BsPl V1, V0, H1, H0; };
 
-// one anti-diagonal.  TRACK: also produce the decision planes (N: not diagonal; G: deletion if N, else mismatch)
-template <bool ODD, bool TRACK>
-__device__ __forceinline__ void bs_step(BsState &x, const BsStream &st, uint64_t &N, uint64_t &G) {
-    uint64_t u1, u0, w1, w0;
-    if (!ODD) { u1 = x.H1 << 1; u0 = x.H0 << 1; w1 = x.V1; w0 = x.V0; }
-    else      { u1 = x.H1; u0 = x.H0; w1 = x.V1 >> 1; w0 = x.V0 >> 1; }
-    const uint64_t m = ~((st.Qlo ^ st.Dlo) | (st.Qhi ^ st.Dhi));
-    const uint64_t d0 = u0 ^ w0, b0 = ~u0 & w0, t1 = u1 ^ w1, d1 = t1 ^ b0;
-    const uint64_t lt = (~u1 & w1) | (~t1 & b0);
-    const uint64_t big = u1 | w1, nd = ~m & big, del = nd & lt, ins = nd & ~lt, n1 = d1 ^ d0;
-    const uint64_t V1 = (m & ~u1) | (del & n1), V0 = (~nd & ~u0) | (del & d0);
-    const uint64_t H1 = (m & ~w1) | (ins & d1), H0 = (~nd & ~w0) | (ins & d0);
-    const uint64_t Bm = st.Qs | st.Ds;
-    x.V1 = V1 & ~Bm; x.V0 = V0 | Bm; x.H1 = H1 & ~Bm; x.H0 = H0 | Bm;
-    if (TRACK) { N = nd; G = del | ~(m | big); }
+// gfx950 v_bitop3_b32: any boolean function of three words in one instruction; the table is the
+// function evaluated on A = 0xF0, B = 0xCC, C = 0xAA
+enum : uint32_t { TA = 0xF0u, TB = 0xCCu, TC = 0xAAu };
+#define BS_LOP3(a, b, c, EXPR) __builtin_amdgcn_bitop3_b32((a), (b), (c), (uint32_t) (EXPR) & 0xFFu)
+
+// one 32-bit half of an anti-diagonal: u = H of the lower neighbour, w = V of the upper one
+template <bool BOUND, bool TRACK>
+__device__ __forceinline__ void bs_half(uint32_t u1, uint32_t u0, uint32_t w1, uint32_t w0, uint32_t ql, uint32_t qh,
+                                        uint32_t dl, uint32_t dh, uint32_t bm, uint32_t &V1, uint32_t &V0,
+                                        uint32_t &H1, uint32_t &H0, uint32_t &N, uint32_t &G) {
+    const uint32_t e1 = ql ^ dl;
+    const uint32_t m = BS_LOP3(e1, qh, dh, ~TA & ~(TB ^ TC));              // bases equal
+    const uint32_t b0 = BS_LOP3(u0, w0, w0, ~TA & TB);                     // borrow of the low code bit
+    const uint32_t lt = BS_LOP3(u1, w1, b0, ((TA ^ TB) & TB) | (~(TA ^ TB) & TC));   // u < w
+    const uint32_t nd = BS_LOP3(m, u1, w1, ~TA & (TB | TC));               // a gap beats the mismatch diagonal
+    const uint32_t d0 = u0 ^ w0;
+    const uint32_t d1 = BS_LOP3(u1, w1, b0, TA ^ TB ^ TC);                 // (u - w) mod 4 = d1 d0
+    const uint32_t del = nd & lt;
+    const uint32_t a = BS_LOP3(del, d1, d0, TA & (TB ^ TC));               // high bit of w - u, deletions only
+    uint32_t v1 = BS_LOP3(a, m, u1, TA | (TB & ~TC));
+    const uint32_t hh = BS_LOP3(nd, lt, d1, TA & ~TB & TC);
+    uint32_t h1 = BS_LOP3(hh, m, w1, TA | (TB & ~TC));
+    const uint32_t x = BS_LOP3(nd, lt, d0, TA & TB & TC);
+    uint32_t v0 = BS_LOP3(x, nd, u0, TA | (~(TB | TC) & 0xFFu));
+    const uint32_t xx = BS_LOP3(nd, lt, d0, TA & ~TB & TC);
+    uint32_t h0 = BS_LOP3(xx, nd, w0, TA | (~(TB | TC) & 0xFFu));
+    if (BOUND) {                                                           // free-exit points: V = H = 0 (code 1)
+        v1 = BS_LOP3(v1, bm, bm, TA & ~TB);  v0 |= bm;
+        h1 = BS_LOP3(h1, bm, bm, TA & ~TB);  h0 |= bm;
+    }
+    V1 = v1; V0 = v0; H1 = h1; H0 = h0;
+    if (TRACK) { N = nd; G = BS_LOP3(nd, lt, m, (TA & TB) | (~TA & TC)); }   // G: deletion if N, else MATCH
+}
+
+// one anti-diagonal.  TRACK: also produce the decision planes
+template <bool ODD, bool BOUND, bool TRACK>
+__device__ __forceinline__ void bs_step(BsState &x, const BsStream &st, BsPl &N, BsPl &G) {
+    BsPl u1, u0, w1, w0;
+    if (!ODD) {                        // u = H << 1 (the lowest lattice point has no insertion neighbour in the band)
+        u1.lo = x.H1.lo << 1; u1.hi = bs_alignbit(x.H1.hi, x.H1.lo, 31);
+        u0.lo = x.H0.lo << 1; u0.hi = bs_alignbit(x.H0.hi, x.H0.lo, 31);
+        w1 = x.V1; w0 = x.V0;
+    } else {                           // w = V >> 1 (the highest one has no deletion neighbour)
+        u1 = x.H1; u0 = x.H0;
+        w1.lo = bs_alignbit(x.V1.hi, x.V1.lo, 1); w1.hi = x.V1.hi >> 1;
+        w0.lo = bs_alignbit(x.V0.hi, x.V0.lo, 1); w0.hi = x.V0.hi >> 1;
+    }
+    const uint32_t bl = BOUND ? (st.Qs.lo | st.Ds.lo) : 0u, bh = BOUND ? (st.Qs.hi | st.Ds.hi) : 0u;
+    bs_half<BOUND, TRACK>(u1.lo, u0.lo, w1.lo, w0.lo, st.Qlo.lo, st.Qhi.lo, st.Dlo.lo, st.Dhi.lo, bl,
+                          x.V1.lo, x.V0.lo, x.H1.lo, x.H0.lo, N.lo, G.lo);
+    bs_half<BOUND, TRACK>(u1.hi, u0.hi, w1.hi, w0.hi, st.Qlo.hi, st.Qhi.hi, st.Dlo.hi, st.Dhi.hi, bh,
+                          x.V1.hi, x.V0.hi, x.H1.hi, x.H0.hi, N.hi, G.hi);
 }
 
 __device__ __forceinline__ int bs_wave_max(int v) {
@@ -197,6 +245,18 @@ __device__ __forceinline__ int bs_wave_max(int v) {
 // ----------------------------------------------------------------------------------------
 // the kernel: one wavefront per workgroup, lane = read
 // ----------------------------------------------------------------------------------------
+// everything a traceback block needs from memory, fetched one block ahead (during the previous walk)
+struct BsBlockRaw { BsPair q0, q1, q2, d0, d1, d2; uint32_t ck[8]; };
+
+__device__ __forceinline__ void bs_block_prefetch(BsBlockRaw &raw, const BsTile &t, int c, const uint32_t *ckw, int lane) {
+    const int A0 = BS_H * (c + 1) + 31, b_lo = BS_H * c - 32;      // anti-diagonal K(c+1)-1: A0, and B0 - K/2
+    raw.q0 = bs_q_raw(t, A0); raw.q1 = bs_q_raw(t, A0 - 32); raw.q2 = bs_q_raw(t, A0 - 64);
+    raw.d0 = bs_d_raw(t, b_lo); raw.d1 = bs_d_raw(t, b_lo + 32); raw.d2 = bs_d_raw(t, b_lo + 64);
+    const uint32_t *cp = ckw + (size_t) c * 512 + lane;      // checkpoint c+1 = state after anti-diagonal K(c+1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) raw.ck[e] = cp[64 * e];
+}
+
 __global__ __launch_bounds__(64) void gact_bs_kernel(const uint64_t *__restrict__ qpl, uint64_t wpr,
                                                      const uint32_t *__restrict__ lens,
                                                      const lrm_seq_meta *__restrict__ meta,
@@ -204,43 +264,43 @@ __global__ __launch_bounds__(64) void gact_bs_kernel(const uint64_t *__restrict_
                                                      const uint64_t *__restrict__ cpl,
                                                      const uint32_t *__restrict__ tlens,
                                                      const uint32_t *__restrict__ rflags, uint64_t n_reads,
-                                                     int T, int O, uint8_t *__restrict__ store,
-                                                     uint64_t store_stride, int32_t *__restrict__ n_ops_out,
+                                                     int T, int O, uint32_t *__restrict__ ckpt,
+                                                     uint64_t *__restrict__ codes, uint64_t cw,
+                                                     int32_t *__restrict__ n_codes_out,
+                                                     int32_t *__restrict__ n_ops_out,
                                                      int32_t *__restrict__ score_out, LrmDevCounters *counters) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t ck[];      // [checkpoint][plane][lane]
     const int lane = threadIdx.x;
     const uint64_t r = (uint64_t) blockIdx.x * 64 + (uint64_t) lane;
     const uint64_t rs = r < n_reads ? r : 0;
     const bool fenced = r < n_reads && meta_r[rs] == 0;
     bool alive = r < n_reads && !fenced && !(rflags && rflags[rs]);
-    if (fenced) { n_ops_out[r] = 0; score_out[r] = -1; }
+    if (fenced) { n_ops_out[r] = 0; score_out[r] = -1; n_codes_out[r] = 0; }
     const int n = alive ? (int) lens[rs] : 0;
     const int m = alive ? (tlens ? (int) tlens[rs] : n) : 0;
     const int64_t loc = alive ? (int64_t) meta[rs].loc : 0;
-    uint8_t *out = store + rs * store_stride;
+    uint64_t *cout = codes + rs * cw;                           // 2-bit CIGAR codes, 32 per word
     BsTile t;
     t.qpl = qpl + rs * wpr + BS_PADW;
     t.dpl = cpl;
 
     const int cap = T - O, lim2 = 2 * cap;
     const int nblk = (lim2 + BS_K - 1) / BS_K;
+    uint32_t *ckw = ckpt + (size_t) blockIdx.x * (size_t) nblk * 512;   // this wavefront's checkpoints (L2-resident scratch)
     int i = 0, j = 0, cnt = 0, score = 0;
-    uint32_t wbuf = 0;
+    uint64_t sb = 0;               // code stream buffer: `fill` bits used
+    int fill = 0, widx = 0;
+    uint64_t pend = 0;             // a full code word whose store is delayed past the next block's loads
+    bool has_pend = false;
     unsigned tiles = 0;
-
-#define BS_EMIT(OP) do {                                                             \
-        wbuf |= (uint32_t) (OP) << ((cnt & 3) * 8);                                      \
-        cnt++;                                                                           \
-        if ((cnt & 3) == 0) { *reinterpret_cast<uint32_t *>(out + cnt - 4) = wbuf; wbuf = 0; } \
-    } while (0)
 
     while (true) {
         if (alive && (score < 0 || !(i < n && j < m))) {          // this lane's read is finished: write it out
-            if (score >= 0) while (i < n) { BS_EMIT('I'); score++; i++; }     // text exhausted
-            const int tail = cnt & 3;
-            for (int e = 0; e < tail; ++e) out[cnt - tail + e] = (uint8_t) (wbuf >> (8 * e));
-            n_ops_out[r] = score >= 0 ? cnt : 0;
-            score_out[r] = score;
+            if (has_pend) { cout[widx++] = pend; has_pend = false; }
+            if (fill > 0) cout[widx] = sb;
+            const int rest = score >= 0 ? n - i : 0;               // text exhausted: the expansion appends 'I's
+            n_codes_out[r] = score >= 0 ? cnt : 0;
+            n_ops_out[r] = score >= 0 ? cnt + rest : 0;
+            score_out[r] = score >= 0 ? score + rest : score;
             alive = false;
         }
         const bool act = alive;
@@ -252,70 +312,120 @@ __global__ __launch_bounds__(64) void gact_bs_kernel(const uint64_t *__restrict_
         t.tq = act ? min(T, n - i) : 0;
         t.tt = act ? min(T, m - j) : 0;
         const bool last = i + t.tq == n;
-        const int S0 = (bs_wave_max(t.tq + t.tt) + BS_K - 1) & ~(BS_K - 1);
+        const int S0 = ((bs_wave_max(t.tq + t.tt) + BS_K - 1) / BS_K) * BS_K;
         const int nb = min(nblk, S0 / BS_K);
 
-        BsState x = {0ull, ~0ull, 0ull, ~0ull};
+        BsState x = {{0u, 0u}, {~0u, ~0u}, {0u, 0u}, {~0u, ~0u}};
         BsStream st;
-        uint64_t nN, nG;
+        BsPl nN, nG;
         // ---- pass 1: differences only, checkpoints at the block boundaries ----
         bs_stream_init(st, t, S0, 31);
+        BsPair pq = bs_q_raw(t, st.qnext), pd = bs_d_raw(t, st.dnext);      // next stream words, one refill ahead
         uint32_t shq = 0, shd = 31;
+        bool hb = bs_any_sentinel(st);
+        int ck_s = nb * BS_K;                                      // next anti-diagonal whose state is kept
         for (int s = S0;; s -= 2) {
-            bs_step<false, false>(x, st, nN, nG);
-            if ((s & (BS_K - 1)) == 0 && (s >> 5) <= nb) {
-                uint64_t *c = ck + (size_t) (s >> 5) * 256 + lane;
-                c[0] = x.V1; c[64] = x.V0; c[128] = x.H1; c[192] = x.H0;
+            if (hb) bs_step<false, true, false>(x, st, nN, nG); else bs_step<false, false, false>(x, st, nN, nG);
+            if (s == ck_s) {
+                uint32_t *c_ = ckw + (size_t) (s / BS_K - 1) * 512 + lane;
+                c_[0] = x.V1.lo; c_[64] = x.V1.hi; c_[128] = x.V0.lo; c_[192] = x.V0.hi;
+                c_[256] = x.H1.lo; c_[320] = x.H1.hi; c_[384] = x.H0.lo; c_[448] = x.H0.hi;
+                ck_s -= BS_K;
             }
             if (s == BS_K) break;
             if (++shq == 32) {
-                st.q0 = st.q1; st.q1 = st.q2; st.q2 = bs_q_word(t, st.qnext);
+                st.q0 = st.q1; st.q1 = st.q2; st.q2 = bs_q_conv(t, st.qnext, pq);
                 st.qnext -= 32;
+                pq = bs_q_raw(t, st.qnext);
                 shq = 0;
+                hb = bs_any_sentinel(st);
+                if (hb) bs_extract_d<true>(st, shd);          // the text sentinel window may not be current
             }
-            bs_extract_q(st, shq);
-            bs_step<true, false>(x, st, nN, nG);
+            if (hb) {
+                bs_extract_q<true>(st, shq);
+                bs_step<true, true, false>(x, st, nN, nG);
+            } else {
+                bs_extract_q<false>(st, shq);
+                bs_step<true, false, false>(x, st, nN, nG);
+            }
             if (shd == 0) {
-                st.d2 = st.d1; st.d1 = st.d0; st.d0 = bs_d_word(t, st.dnext);
+                st.d2 = st.d1; st.d1 = st.d0; st.d0 = bs_d_conv(t, st.dnext, pd);
                 st.dnext -= 32;
+                pd = bs_d_raw(t, st.dnext);
                 shd = 32;
+                hb = bs_any_sentinel(st);
+                if (hb) bs_extract_q<true>(st, shq);          // the query sentinel window may not be current
             }
             --shd;
-            bs_extract_d(st, shd);
+            if (hb) bs_extract_d<true>(st, shd); else bs_extract_d<false>(st, shd);
         }
         // ---- pass 2: per block recompute with decision planes, then walk through the block ----
         int a = 0, b = 0;
         bool running = act;
+        BsBlockRaw raw;
+        bs_block_prefetch(raw, t, 0, ckw, lane);
         for (int c = 0; c < nb; ++c) {
             if (__ballot(running) == 0) break;
             {
-                const uint64_t *cp = ck + (size_t) (c + 1) * 256 + lane;
-                x.V1 = cp[0]; x.V0 = cp[64]; x.H1 = cp[128]; x.H0 = cp[192];
+                const int A0 = BS_H * (c + 1) + 31, b_lo = BS_H * c - 32;
+                st.q0 = bs_q_conv(t, A0, raw.q0); st.q1 = bs_q_conv(t, A0 - 32, raw.q1); st.q2 = bs_q_conv(t, A0 - 64, raw.q2);
+                st.d0 = bs_d_conv(t, b_lo, raw.d0); st.d1 = bs_d_conv(t, b_lo + 32, raw.d1); st.d2 = bs_d_conv(t, b_lo + 64, raw.d2);
+                x.V1.lo = raw.ck[0]; x.V1.hi = raw.ck[1]; x.V0.lo = raw.ck[2]; x.V0.hi = raw.ck[3];
+                x.H1.lo = raw.ck[4]; x.H1.hi = raw.ck[5]; x.H0.lo = raw.ck[6]; x.H0.hi = raw.ck[7];
+                bs_extract_q<true>(st, 0);
+                bs_extract_d<true>(st, BS_H);
             }
-            bs_stream_init(st, t, BS_K * c + BS_K - 1, 16);
-            uint64_t N[BS_K], G[BS_K];
+            // the previous block's full code word goes out here, behind the loads it must not delay
+            if (has_pend) { cout[widx++] = pend; has_pend = false; }
+            BsPl N[BS_K], G[BS_K];
+            if (bs_any_sentinel(st)) {
 #pragma unroll
-            for (int k = BS_K - 1; k >= 1; k -= 2) {
-                bs_step<true, true>(x, st, N[k], G[k]);
-                bs_extract_d(st, (uint32_t) ((k - 1) >> 1));                 // 15 .. 0
-                bs_step<false, true>(x, st, N[k - 1], G[k - 1]);
-                if (k > 1) bs_extract_q(st, (uint32_t) (16 - ((k - 1) >> 1)));   // 1 .. 15
+                for (int k = BS_K - 1; k >= 1; k -= 2) {
+                    bs_step<true, true, true>(x, st, N[k], G[k]);
+                    bs_extract_d<true>(st, (uint32_t) ((k - 1) >> 1));                 // K/2-1 .. 0
+                    bs_step<false, true, true>(x, st, N[k - 1], G[k - 1]);
+                    if (k > 1) bs_extract_q<true>(st, (uint32_t) (BS_H - ((k - 1) >> 1)));   // 1 .. K/2-1
+                }
+            } else {
+#pragma unroll
+                for (int k = BS_K - 1; k >= 1; k -= 2) {
+                    bs_step<true, false, true>(x, st, N[k], G[k]);
+                    bs_extract_d<false>(st, (uint32_t) ((k - 1) >> 1));
+                    bs_step<false, false, true>(x, st, N[k - 1], G[k - 1]);
+                    if (k > 1) bs_extract_q<false>(st, (uint32_t) (BS_H - ((k - 1) >> 1)));
+                }
             }
+            if (c + 1 < nb) bs_block_prefetch(raw, t, c + 1, ckw, lane);
+            // walk: the lane's path crosses each anti-diagonal at most once; codes 0 X, 1 =, 2 I, 3 D
             int sw = a + b - BS_K * c;
+            uint64_t bw = 0;
+            int e2 = 0;
 #pragma unroll
             for (int k = 0; k < BS_K; ++k) {
                 if (running && sw == k) {
                     const uint32_t tpos = (uint32_t) (b - a + 64) >> 1;
-                    const uint32_t nbit = (uint32_t) (N[k] >> tpos) & 1u, gbit = (uint32_t) (G[k] >> tpos) & 1u;
-                    const uint32_t op = nbit ? (gbit ? 'D' : 'I') : (gbit ? 'X' : '=');
-                    BS_EMIT(op);
-                    score += (int) (nbit | gbit);
-                    a += (int) (1u ^ (nbit & gbit));
-                    b += (int) (1u ^ (nbit & (gbit ^ 1u)));
+                    const bool up = tpos >= 32u;
+                    const uint32_t nbit = __builtin_amdgcn_ubfe(up ? N[k].hi : N[k].lo, tpos & 31u, 1u);
+                    const uint32_t gbit = __builtin_amdgcn_ubfe(up ? G[k].hi : G[k].lo, tpos & 31u, 1u);
+                    const uint32_t code = nbit * 2u + gbit;
+                    bw |= (uint64_t) code << e2;
+                    e2 += 2;
+                    score += code != 1u;
+                    a += code != 3u;
+                    b += code != 2u;
                     sw = a + b - BS_K * c;
                     running = a < t.tq && b < t.tt && (last ? (a + b < lim2) : (a < cap && b < cap));
                 }
             }
+            // append the block's codes (at most 32) to the lane's code stream
+            sb |= bw << fill;
+            cnt += e2 >> 1;
+            if (fill + e2 >= 64) {
+                pend = sb; has_pend = true;
+                sb = (bw >> 1) >> (63 - fill);
+                fill -= 64;
+            }
+            fill += e2;
         }
         if (act) {
             i += a;
@@ -323,8 +433,33 @@ __global__ __launch_bounds__(64) void gact_bs_kernel(const uint64_t *__restrict_
             if (a + b == 0) score = -1;                           // cannot happen (every walk moves); never spin
         }
     }
-#undef BS_EMIT
     if (lane == 0 && tiles) atomicAdd(&counters->gact_tiles, (unsigned long long) tiles);
+}
+
+// codes -> CIGAR bytes ('=' 'X' 'I' 'D', one per alignment column): one thread per four columns
+__global__ __launch_bounds__(256) void bs_expand_kernel(const uint64_t *__restrict__ codes, uint64_t cw,
+                                                        const int32_t *__restrict__ n_codes,
+                                                        const int32_t *__restrict__ n_ops,
+                                                        const uint32_t *__restrict__ rflags,
+                                                        const int32_t *__restrict__ meta_r, uint64_t n_reads,
+                                                        uint32_t blocks_per_read, uint8_t *__restrict__ store,
+                                                        uint64_t store_stride) {
+    const uint64_t r = blockIdx.x / blocks_per_read;
+    if (r >= n_reads) return;
+    if (meta_r[r] == 0 || (rflags && rflags[r])) return;         // fenced, or written by the byte kernel
+    const int no = n_ops[r], nc = n_codes[r];
+    const int o = (int) ((blockIdx.x % blocks_per_read) * 256 + threadIdx.x) * 4;
+    if (o >= no) return;
+    const uint32_t c8 = (uint32_t) (codes[r * cw + (uint64_t) (o >> 5)] >> ((o & 31) * 2)) & 0xffu;
+    uint32_t w = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t op = o + e < nc ? __builtin_amdgcn_ubfe(0x44493d58u, ((c8 >> (2 * e)) & 3u) * 8u, 8u) : (uint32_t) 'I';
+        w |= op << (8 * e);
+    }
+    uint8_t *out = store + r * store_stride + o;
+    if (o + 4 <= no) *reinterpret_cast<uint32_t *>(out) = w;
+    else for (int e = 0; o + e < no; ++e) out[e] = (uint8_t) (w >> (8 * e));
 }
 
 // ----------------------------------------------------------------------------------------
@@ -397,22 +532,21 @@ int lrm_bs_pack_reads(const char *d_reads, uint64_t stride, const uint32_t *d_le
     return 0;
 }
 
-int lrm_bs_launch(const uint64_t *d_qpl, uint64_t wpr, const uint32_t *d_lens, const lrm_seq_meta *d_meta,
-                  const int32_t *d_meta_r, const uint64_t *d_cpl, const uint32_t *d_tlens, const uint32_t *d_flags,
-                  uint64_t n, int T, int O, uint8_t *d_store, uint64_t store_stride, int32_t *d_n_ops,
-                  int32_t *d_score, LrmDevCounters *counters, void *stream_) {
+uint64_t lrm_bs_code_words(uint32_t max_len) { return (2ull * max_len + 31) / 32 + 2; }
+uint64_t lrm_bs_ckpt_words(uint64_t n) { return ((n + 63) / 64) * (uint64_t) (1024 / BS_K) * 512ull; }   // T - O <= 512
+
+int lrm_bs_launch(const LrmBsArgs *bs, const uint32_t *d_lens, const lrm_seq_meta *d_meta, const int32_t *d_meta_r,
+                  const uint32_t *d_tlens, uint64_t n, int T, int O, uint8_t *d_store, uint64_t store_stride,
+                  int32_t *d_n_ops, int32_t *d_score, LrmDevCounters *counters, void *stream_) {
     hipStream_t stream = (hipStream_t) stream_;
-    const int nblk = (2 * (T - O) + BS_K - 1) / BS_K;
-    const size_t shmem = (size_t) (nblk + 1) * 256 * 8;
     const uint64_t blocks = (n + 63) / 64;
     if (blocks > 0x7fffffffull) { lrm_set_error("gact grid too large: split the batch"); return -1; }
-    if (shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gact_bs_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
-        if (e != hipSuccess) { lrm_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", shmem, hipGetErrorString(e)); return -1; }
-    }
-    hipLaunchKernelGGL(gact_bs_kernel, dim3((uint32_t) blocks), dim3(64), shmem, stream, d_qpl, wpr, d_lens, d_meta,
-                       d_meta_r, d_cpl + BS_PADW, d_tlens, d_flags, n, T, O, d_store, store_stride, d_n_ops, d_score,
-                       counters);
+    hipLaunchKernelGGL(gact_bs_kernel, dim3((uint32_t) blocks), dim3(64), 0, stream, bs->qpl, bs->wpr, d_lens, d_meta,
+                       d_meta_r, bs->cpl + BS_PADW, d_tlens, bs->flags, n, T, O, bs->ckpt, bs->codes, bs->cw,
+                       bs->ncodes, d_n_ops, d_score, counters);
+    const uint32_t bpr = (uint32_t) ((bs->cw * 32 + 1023) / 1024);
+    if (n * bpr > 0x7fffffffull) { lrm_set_error("expand grid too large: split the batch"); return -1; }
+    hipLaunchKernelGGL(bs_expand_kernel, dim3((uint32_t) (n * bpr)), dim3(256), 0, stream, bs->codes, bs->cw, bs->ncodes,
+                       d_n_ops, bs->flags, d_meta_r, n, bpr, d_store, store_stride);
     return 0;
 }

@@ -828,8 +828,8 @@ static int gact_launch(lrm_gact_params gp, uint64_t n, hipStream_t stream, const
     // (below ~16 k reads the two-reads-per-wavefront kernel finishes first).
     const bool bs_ok = bs && bs->cpl && gp.W == 128 && (((uintptr_t) store | (uintptr_t) store_stride) & 3u) == 0;
     if (bs_ok && (impl == 4 || (impl == 0 && n >= LRM_BS_MIN_READS))) {
-        if (lrm_bs_launch(bs->qpl, bs->wpr, lens, meta, meta_r, bs->cpl, tlens, bs->flags, n, gp.T, gp.O, store,
-                          store_stride, n_ops, score, counters, stream)) return -1;
+        if (lrm_bs_launch(bs, lens, meta, meta_r, tlens, n, gp.T, gp.O, store, store_stride, n_ops, score, counters,
+                          stream)) return -1;
         // reads holding a byte other than ACGT (rare): byte kernel, flagged reads only
         GactLds L1 = gact_lds_layout(gp.T, gp.O);
         size_t sh1 = (size_t) L1.wave_bytes * 4;
@@ -905,7 +905,7 @@ int lrm_launch_extend(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint64_t
                            d_lens, d_meta, d_meta_r, n, cpr);
         lrm_time_end(ws, stream);
     }
-    LrmBsArgs bs = {nullptr, 0, nullptr, nullptr};
+    LrmBsArgs bs = {};
     const bool want_bs = lrm_bs_wanted(gp, n) && idx->d_cpl && idx->cpl_ok && ws->d_qpl && n <= ws->n_max &&
                          max_len <= ws->max_len;
     if (want_bs) {
@@ -913,6 +913,7 @@ int lrm_launch_extend(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint64_t
         if (lrm_bs_pack_reads(d_reads, stride, d_lens, n, max_len, ws->d_qpl, ws->qpl_wpr, ws->d_rflags, stream)) return -1;
         lrm_time_end(ws, stream);
         bs.qpl = ws->d_qpl; bs.wpr = ws->qpl_wpr; bs.flags = ws->d_rflags; bs.cpl = idx->d_cpl;
+        bs.ckpt = ws->d_ckpt; bs.codes = ws->d_codes; bs.cw = ws->codes_cw; bs.ncodes = ws->d_ncodes;
     }
     const bool runs_bs = want_bs && (((uintptr_t) d_store | (uintptr_t) store_stride) & 3u) == 0;
     lrm_time_begin(ws, runs_bs ? LRM_K_GACT_BS : LRM_K_GACT, stream);
@@ -963,9 +964,9 @@ extern "C" int lrm_debug_gact(const char *q, int n, const char *d, int m, lrm_ga
     HIPCHK(hipMemcpy(dl, hl, 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dm, &hm, sizeof(hm), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dr, hr, 12, hipMemcpyHostToDevice));
-    LrmBsArgs bs = {nullptr, 0, nullptr, nullptr};
-    uint64_t *dqpl = nullptr, *dcpl = nullptr;
-    uint32_t *dfl = nullptr;
+    LrmBsArgs bs = {};
+    uint64_t *dqpl = nullptr, *dcpl = nullptr, *dcodes = nullptr;
+    uint32_t *dfl = nullptr, *dck = nullptr;
     if (lrm_bs_wanted(gp, 1)) {
         const uint64_t wq = lrm_bs_planar_words((uint64_t) n), wd = lrm_bs_planar_words((uint64_t) m);
         HIPCHK(hipMalloc(&dqpl, wq * 8 + 16));
@@ -976,6 +977,10 @@ extern "C" int lrm_debug_gact(const char *q, int n, const char *d, int m, lrm_ga
         uint32_t tf = 0;
         HIPCHK(hipMemcpy(&tf, dfl + 1, 4, hipMemcpyDeviceToHost));
         bs.qpl = dqpl; bs.wpr = wq; bs.flags = dfl; bs.cpl = tf ? nullptr : dcpl;
+        bs.cw = lrm_bs_code_words((uint32_t) (n > m ? n : m));
+        HIPCHK(hipMalloc(&dcodes, bs.cw * 8 + 16));
+        HIPCHK(hipMalloc(&dck, lrm_bs_ckpt_words(1) * 4));
+        bs.codes = dcodes; bs.ckpt = dck; bs.ncodes = (int32_t *) (dfl + 2);
     }
     if (gact_launch(gp, 1, 0, dq, 0, dl, dm, dr, dd, dl + 1, dops, 0, dr + 1, dr + 2, dc, bs.qpl ? &bs : nullptr)) return -1;
     HIPCHK(hipGetLastError());
@@ -989,5 +994,7 @@ extern "C" int lrm_debug_gact(const char *q, int n, const char *d, int m, lrm_ga
     if (dqpl) (void) hipFree(dqpl);
     if (dcpl) (void) hipFree(dcpl);
     if (dfl) (void) hipFree(dfl);
+    if (dcodes) (void) hipFree(dcodes);
+    if (dck) (void) hipFree(dck);
     return 0;
 }

@@ -268,6 +268,7 @@ extern "C" void lrm_workspace_free(lrm_workspace *ws) {
     (void) hipFree(ws->d_reads2); (void) hipFree(ws->d_rec); (void) hipFree(ws->d_phase); (void) hipFree(ws->d_decided);
     (void) hipFree(ws->d_hcount); (void) hipFree(ws->d_counters);
     (void) hipFree(ws->d_qpl); (void) hipFree(ws->d_rflags);
+    (void) hipFree(ws->d_ckpt); (void) hipFree(ws->d_codes); (void) hipFree(ws->d_ncodes);
     for (int i = 0; i < LRM_MAX_TIMED; ++i) {
         if (ws->ev_start[i]) (void) hipEventDestroy((hipEvent_t) ws->ev_start[i]);
         if (ws->ev_stop[i]) (void) hipEventDestroy((hipEvent_t) ws->ev_stop[i]);
@@ -295,6 +296,7 @@ extern "C" int lrm_workspace_create(lrm_workspace **out, lrm_index *idx, uint64_
     if (ws->cap_q == 0) ws->cap_q = 1;
     ws->words_per_read = (uint64_t) max_len / 32 + 2;
     ws->qpl_wpr = lrm_bs_planar_words(max_len);
+    ws->codes_cw = lrm_bs_code_words(max_len);
     struct { void **p; uint64_t bytes; } allocs[] = {
         {(void **) &ws->d_reads2, n_max * ws->words_per_read * 8},
         {(void **) &ws->d_rec, n_max * (uint64_t) ws->P * ws->cap_q * 8},
@@ -304,6 +306,9 @@ extern "C" int lrm_workspace_create(lrm_workspace **out, lrm_index *idx, uint64_
         {(void **) &ws->d_counters, sizeof(LrmDevCounters)},
         {(void **) &ws->d_qpl, n_max * ws->qpl_wpr * 8 + 16},
         {(void **) &ws->d_rflags, n_max * 4},
+        {(void **) &ws->d_ckpt, lrm_bs_ckpt_words(n_max) * 4},
+        {(void **) &ws->d_codes, n_max * ws->codes_cw * 8},
+        {(void **) &ws->d_ncodes, n_max * 4},
     };
     for (auto &a : allocs) {
         if (hipMalloc(a.p, a.bytes) != hipSuccess) {

@@ -133,20 +133,32 @@ struct lrm_workspace {
     uint64_t *d_qpl;
     uint64_t qpl_wpr;
     uint32_t *d_rflags;
+    uint32_t *d_ckpt;        // checkpoint scratch of the bit-sliced kernel
+    uint64_t *d_codes;       // 2-bit CIGAR codes (expanded to bytes by bs_expand_kernel)
+    uint64_t codes_cw;
+    int32_t *d_ncodes;
 };
 
 #define LRM_BS_PADW 24       // planar words of padding on either side of a packed sequence
 #define LRM_BS_MIN_READS 16384
-struct LrmBsArgs { const uint64_t *qpl; uint64_t wpr; const uint32_t *flags; const uint64_t *cpl; };
+struct LrmBsArgs {
+    const uint64_t *qpl; uint64_t wpr;     // planar reads
+    const uint32_t *flags;                 // per read: holds a byte other than ACGT
+    const uint64_t *cpl;                   // planar text
+    uint32_t *ckpt;                        // checkpoint scratch, lrm_bs_ckpt_words(n) words
+    uint64_t *codes; uint64_t cw;          // 2-bit CIGAR codes, cw words per read
+    int32_t *ncodes;                       // codes per read (the rest of n_ops is the 'I' tail)
+};
 uint64_t lrm_bs_planar_words(uint64_t len);
+uint64_t lrm_bs_code_words(uint32_t max_len);
+uint64_t lrm_bs_ckpt_words(uint64_t n);
 bool lrm_bs_wanted(lrm_gact_params gp, uint64_t n);      // W = 128 and (LRM_GACT_IMPL=4 or automatic with a large batch)
 int lrm_bs_pack_reads(const char *d_reads, uint64_t stride, const uint32_t *d_lens, uint64_t n, uint32_t max_len,
                       uint64_t *d_qpl, uint64_t wpr, uint32_t *d_flags, void *stream);
 int lrm_bs_pack_text(const char *d_text, uint64_t len, uint64_t *d_out, uint32_t *d_flag, void *stream);
-int lrm_bs_launch(const uint64_t *d_qpl, uint64_t wpr, const uint32_t *d_lens, const lrm_seq_meta *d_meta,
-                  const int32_t *d_meta_r, const uint64_t *d_cpl, const uint32_t *d_tlens, const uint32_t *d_flags,
-                  uint64_t n, int T, int O, uint8_t *d_store, uint64_t store_stride, int32_t *d_n_ops,
-                  int32_t *d_score, LrmDevCounters *counters, void *stream);
+int lrm_bs_launch(const LrmBsArgs *bs, const uint32_t *d_lens, const lrm_seq_meta *d_meta, const int32_t *d_meta_r,
+                  const uint32_t *d_tlens, uint64_t n, int T, int O, uint8_t *d_store, uint64_t store_stride,
+                  int32_t *d_n_ops, int32_t *d_score, LrmDevCounters *counters, void *stream);
 int lrm_bs_prepare_index(lrm_index *idx);
 void lrm_bs_free_index(lrm_index *idx);
 

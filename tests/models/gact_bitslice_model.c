@@ -20,7 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define BS_K 32                 /* anti-diagonals per traceback block */
+#define BS_K 16                 /* anti-diagonals per traceback block (the kernel's value) */
 #define BS_PAD 8                /* planar words of padding on either side of a sequence */
 
 typedef struct { uint32_t lo, hi; } bs_word;      /* 32 bases: bit k of lo/hi = low/high code bit of base k */
@@ -192,7 +192,7 @@ int bsm_gact(const char *q, int n, const char *d, int m, int T, int O, int extra
         for (int c = 0; c < nb && running; ++c) {
             uint64_t N[BS_K], G[BS_K];
             x = ckpt[c + 1];
-            stream_init(&st, &t, BS_K * c + BS_K - 1, 16);
+            stream_init(&st, &t, BS_K * c + BS_K - 1, BS_K / 2);
             for (int k = BS_K - 1; k >= 1; k -= 2) {
                 bs_step(&x, &st, 1, &N[k], &G[k]);
                 d_transition(&st, &t);
