@@ -54,8 +54,8 @@ def load_pmc_summary(args, n, Lr):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--ref-len", type=int, default=ECOLI_N)
     ap.add_argument("--reads", type=int, default=100_000)
     ap.add_argument("--read-len", type=int, default=10_000)
@@ -63,6 +63,12 @@ def main():
     ap.add_argument("--seed-len", type=int, default=20)
     ap.add_argument("--thres", type=int, default=300)
     ap.add_argument("--gact", default="320,120,128")
+    ap.add_argument("--isolated-replay", action="store_true",
+                    help="after the timed region, replay the steps serialized on one stream and report the per-kernel "
+                         "table of that replay under `isolated` (same as running --streams 1, in one invocation)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("LRM_BENCH_STREAMS", "3")),
+                    help="HIP streams the steps alternate over (each with its own workspace); >1 overlaps the "
+                         "HBM-latency-bound seed kernels of one step with the VALU-bound extension of another")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0: skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -101,17 +107,27 @@ def main():
     n, Lr = args.reads, args.read_len
     r = synth.reads([ref], n, Lr, prof, seed=11 + 1000 * rank)
     pristine = torch.from_numpy(r["reads"]).to(dev)
-    d_reads = torch.empty_like(pristine)
     d_lens = torch.from_numpy(r["lens"].astype(np.int32)).to(dev)
-    dm = mapper.DeviceMapper(di, n, Lr, args.seed_len, args.thres, gact, device=local)
+    nstreams = max(1, args.streams)
+    slots = []
+    for k in range(nstreams):
+        slots.append(dict(reads=torch.empty_like(pristine),
+                          dm=mapper.DeviceMapper(di, n, Lr, args.seed_len, args.thres, gact, device=local),
+                          stream=torch.cuda.Stream(device=dev) if nstreams > 1 else torch.cuda.current_stream(dev)))
+    dm, d_reads = slots[0]["dm"], slots[0]["reads"]
     bases = int(r["lens"].sum())
     if rank == 0:
         log("reads: %d x %d (%s), workspace %.2f GiB" % (n, Lr, args.profile, dm.workspace_bytes() / 2**30))
 
+    step_no = [0]
+
     def step():
-        d_reads.copy_(pristine)      # extend rev-comps reverse-strand reads in place: restore the batch
-        dm.seed(d_reads, d_lens)
-        dm.extend(d_reads, d_lens)
+        sl = slots[step_no[0] % nstreams]
+        step_no[0] += 1
+        with torch.cuda.stream(sl["stream"]):
+            sl["reads"].copy_(pristine)      # extend rev-comps reverse-strand reads in place: restore the batch
+            sl["dm"].seed(sl["reads"], d_lens)
+            sl["dm"].extend(sl["reads"], d_lens)
 
     def barrier():
         if world > 1:
@@ -122,14 +138,35 @@ def main():
         step()
     barrier()
     if not args.no_kernel_timing:
-        dm.set_timing(True)
+        for sl in slots:
+            sl["dm"].set_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    ktimes = dm.timing() if not args.no_kernel_timing else {}
-    dm.set_timing(False)
+    ktimes = {}
+    if not args.no_kernel_timing:
+        for sl in slots:
+            with torch.cuda.stream(sl["stream"]):
+                for name, (ms, launches) in sl["dm"].timing().items():
+                    a = ktimes.get(name, (0.0, 0))
+                    ktimes[name] = (a[0] + ms, a[1] + launches)
+            sl["dm"].set_timing(False)
+    # serialized replay of the same steps on ONE stream: per-kernel durations without the other streams' kernels
+    # sharing the chip (the timed region above is what `value` and `roofline` come from)
+    ktimes_iso = {}
+    if nstreams > 1 and args.isolated_replay and not args.no_kernel_timing and rank == 0:
+        slots[0]["dm"].set_timing(True)
+        for _ in range(args.steps):
+            with torch.cuda.stream(slots[0]["stream"]):
+                slots[0]["reads"].copy_(pristine)
+                slots[0]["dm"].seed(slots[0]["reads"], d_lens)
+                slots[0]["dm"].extend(slots[0]["reads"], d_lens)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(slots[0]["stream"]):
+            ktimes_iso = slots[0]["dm"].timing()
+        slots[0]["dm"].set_timing(False)
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if tdist.is_initialized() and tdist.get_backend() == "nccl" else "cpu")
     if world > 1:
         tdist.all_reduce(tt, op=tdist.ReduceOp.MAX)
@@ -200,32 +237,34 @@ def main():
     alg_of = {"pack2bit_kernel": per_base["pack2bit"], "seed_search_kernel": per_base["seed_search"],
               "gact_kernel": per_base["gact"], "gact_bs_kernel": per_base["gact"], "bs_pack_reads_kernel": 1.25}
     pmc = load_pmc_summary(args, n, Lr)
-    kernels = {}
-    dominant = None
-    vote_ms = sum(ms for name, (ms, _) in ktimes.items() if name.startswith("vote"))
-    for name, (ms, launches) in ktimes.items():
-        if launches == 0:
-            continue
-        alg = alg_of.get(name)
-        if name.startswith("vote") and vote_ms > 0:
-            alg = per_base["vote"] * ms / vote_ms          # SA bytes apportioned by time over the vote tiers
-        per_launch_bytes = alg * bases * args.steps / launches if alg else None
-        avg_ms = ms / launches
-        k = dict(ms_total=round(ms, 3), launches=launches, avg_ms=round(avg_ms, 4),
-                 algorithmic_bytes_per_launch=per_launch_bytes,
-                 achieved_GBps=(per_launch_bytes / (avg_ms * 1e-3) / 1e9) if per_launch_bytes else None)
-        pk = pmc.get(name.replace("gact_kernel", "gact3_kernel")) if pmc else None
-        if pk:
-            k["traffic_bytes_per_launch"] = (pk["fetch_bytes"] + pk["write_bytes"]) / pk["launches_per_step"]
-            if pk.get("l2_hit") is not None and (pk["l2_hit"] + pk["l2_miss"]) > 0:
-                k["l2_hit_rate"] = pk["l2_hit"] / (pk["l2_hit"] + pk["l2_miss"])
-            if pk.get("valu_insts"):
-                k["valu_wave_insts_per_launch"] = pk["valu_insts"] / pk["launches_per_step"]
-        kernels[name] = k
-        if dominant is None or ms > ktimes[dominant][0]:
-            dominant = name
 
-    def roofline_of(name):
+    def kernel_table(ktimes):
+        kernels, dominant = {}, None
+        vote_ms = sum(ms for name, (ms, _) in ktimes.items() if name.startswith("vote"))
+        for name, (ms, launches) in ktimes.items():
+            if launches == 0:
+                continue
+            alg = alg_of.get(name)
+            if name.startswith("vote") and vote_ms > 0:
+                alg = per_base["vote"] * ms / vote_ms          # SA bytes apportioned by time over the vote tiers
+            per_launch_bytes = alg * bases * args.steps / launches if alg else None
+            avg_ms = ms / launches
+            k = dict(ms_total=round(ms, 3), launches=launches, avg_ms=round(avg_ms, 4),
+                     algorithmic_bytes_per_launch=per_launch_bytes,
+                     achieved_GBps=(per_launch_bytes / (avg_ms * 1e-3) / 1e9) if per_launch_bytes else None)
+            pk = pmc.get(name.replace("gact_kernel", "gact3_kernel")) if pmc else None
+            if pk:
+                k["traffic_bytes_per_launch"] = (pk["fetch_bytes"] + pk["write_bytes"]) / pk["launches_per_step"]
+                if pk.get("l2_hit") is not None and (pk["l2_hit"] + pk["l2_miss"]) > 0:
+                    k["l2_hit_rate"] = pk["l2_hit"] / (pk["l2_hit"] + pk["l2_miss"])
+                if pk.get("valu_insts"):
+                    k["valu_wave_insts_per_launch"] = pk["valu_insts"] / pk["launches_per_step"]
+            kernels[name] = k
+            if dominant is None or ms > ktimes[dominant][0]:
+                dominant = name
+        return kernels, dominant
+
+    def roofline_of(kernels, ktimes, name):
         k = kernels[name]
         ach = k["achieved_GBps"] or 0.0
         r = dict(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
@@ -235,17 +274,26 @@ def main():
             # integer VALU issue: one wave64 instruction per 4 cycles per SIMD, 1024 SIMDs, 2.4 GHz peak clock
             peak_ips = 1024 * 2.4e9 / 4
             r["valu_issue_frac"] = k["valu_wave_insts_per_launch"] / (k["avg_ms"] * 1e-3) / peak_ips
+        if name in ("gact_kernel", "gact_bs_kernel"):
+            r["gcups"] = per_base["cells"] * bases * args.steps / (ktimes[name][0] * 1e-3) / 1e9
+            r["note"] = ("integer DP (gact): bound by VALU issue, not by HBM or MFMA -- its HBM fraction is small by "
+                         "construction (%.1f algorithmic B/base, %.0f cells/base); see valu_issue_frac / gcups"
+                         % (per_base["gact"], per_base["cells"]))
         return r
 
-    roofline = roofline_of(dominant) if dominant else None
-    if dominant in ("gact_kernel", "gact_bs_kernel"):
-        gcups = per_base["cells"] * bases * args.steps / (ktimes[dominant][0] * 1e-3) / 1e9
-        roofline["gcups"] = gcups
-        roofline["note"] = ("dominant kernel is the integer DP (gact): it is bound by VALU issue, not by HBM or MFMA -- "
-                            "its HBM fraction is small by construction (%.1f algorithmic B/base, %.0f cells/base); "
-                            "see valu_issue_frac and roofline_hbm_kernel for the HBM-gather-bound seed_search"
-                            % (per_base["gact"], per_base["cells"]))
-    roofline_hbm = roofline_of("seed_search_kernel") if "seed_search_kernel" in kernels else None
+    kernels, dominant = kernel_table(ktimes)
+    roofline = roofline_of(kernels, ktimes, dominant) if dominant else None
+    roofline_hbm = roofline_of(kernels, ktimes, "seed_search_kernel") if "seed_search_kernel" in kernels else None
+    isolated = None
+    if ktimes_iso:
+        k_iso, dom_iso = kernel_table(ktimes_iso)
+        isolated = dict(note="serialized replay of the same %d steps on one stream after the timed region: per-kernel "
+                             "durations without kernels of other steps sharing the chip" % args.steps,
+                        ms_per_step=sum(v["ms_total"] for v in k_iso.values()) / args.steps,
+                        roofline=roofline_of(k_iso, ktimes_iso, dom_iso),
+                        roofline_hbm_kernel=roofline_of(k_iso, ktimes_iso, "seed_search_kernel"),
+                        roofline_gact=roofline_of(k_iso, ktimes_iso, "gact_bs_kernel") if "gact_bs_kernel" in k_iso else None,
+                        kernels=k_iso)
     total_bases = bases * world * args.steps
     out = dict(metric="aligned Gbp/sec", value=total_bases / elapsed / 1e9, unit="Gbp/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
@@ -255,8 +303,9 @@ def main():
                                     % ({ECOLI_N: "E. coli K-12 sized", CHR1_N: "human chr1 sized"}.get(args.ref_len, "custom"),
                                        args.ref_len, n, Lr, args.profile),
                            seed_len=args.seed_len, thres=args.thres, gact_T=gact[0], gact_O=gact[1], gact_W=gact[2],
-                           reads_per_gpu=n, read_len=Lr, parallelism="reads sharded, index replicated (1 RCCL bcast)"),
+                           reads_per_gpu=n, read_len=Lr, streams=nstreams, parallelism="reads sharded, index replicated (1 RCCL bcast)"),
                roofline=roofline, roofline_hbm_kernel=roofline_hbm, cpu_baseline=cpu, kernels=kernels,
+               isolated=isolated, streams=nstreams,
                algorithmic_bytes_per_base=per_base, stats=stats,
                index_broadcast_s=round(t_bcast, 3), speedup_vs_cpu=(total_bases / elapsed / 1e9) / cpu["value"])
     print(json.dumps(out), flush=True)

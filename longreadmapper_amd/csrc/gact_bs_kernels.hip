@@ -36,6 +36,7 @@
 
 #define BS_K 16                 // anti-diagonals per traceback block (even, <= 32)
 #define BS_H (BS_K / 2)
+#define LRM_BS_MAX_WAVES 2048ull  // 2 per SIMD on 256 CUs
 #define BS_PADW LRM_BS_PADW
 
 struct __attribute__((aligned(8))) BsPair { uint64_t a, b; };
@@ -270,17 +271,17 @@ __global__ __launch_bounds__(64) void gact_bs_kernel(const uint64_t *__restrict_
                                                      int32_t *__restrict__ n_ops_out,
                                                      int32_t *__restrict__ score_out, LrmDevCounters *counters) {
     const int lane = threadIdx.x;
-    const uint64_t r = (uint64_t) blockIdx.x * 64 + (uint64_t) lane;
-    const uint64_t rs = r < n_reads ? r : 0;
-    const bool fenced = r < n_reads && meta_r[rs] == 0;
-    bool alive = r < n_reads && !fenced && !(rflags && rflags[rs]);
-    if (fenced) { n_ops_out[r] = 0; score_out[r] = -1; n_codes_out[r] = 0; }
-    const int n = alive ? (int) lens[rs] : 0;
-    const int m = alive ? (tlens ? (int) tlens[rs] : n) : 0;
-    const int64_t loc = alive ? (int64_t) meta[rs].loc : 0;
-    uint64_t *cout = codes + rs * cw;                           // 2-bit CIGAR codes, 32 per word
+    // Lanes take reads from a queue (one atomic per wavefront and refill): reads of very different
+    // lengths share a wavefront without the short ones idling behind the longest, and a grid of a few
+    // resident wavefronts per SIMD serves any batch size.
+    unsigned long long *queue = &counters->reserved[0];
+    uint64_t r = 0;
+    bool alive = false, exhausted = false;
+    int n = 0, m = 0;
+    int64_t loc = 0;
+    uint64_t *cout = codes;                                     // 2-bit CIGAR codes, 32 per word
     BsTile t;
-    t.qpl = qpl + rs * wpr + BS_PADW;
+    t.qpl = qpl + BS_PADW;
     t.dpl = cpl;
 
     const int cap = T - O, lim2 = 2 * cap;
@@ -302,6 +303,36 @@ __global__ __launch_bounds__(64) void gact_bs_kernel(const uint64_t *__restrict_
             n_ops_out[r] = score >= 0 ? cnt + rest : 0;
             score_out[r] = score >= 0 ? score + rest : score;
             alive = false;
+        }
+        // refill idle lanes from the queue
+        while (true) {
+            const bool need = !alive && !exhausted;
+            const uint64_t needmask = __ballot(need);
+            if (needmask == 0) break;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(queue, (unsigned long long) __popcll(needmask));
+            base = __shfl(base, 0);
+            if (need) {
+                r = base + (uint64_t) __popcll(needmask & ((1ull << lane) - 1ull));
+                if (r >= n_reads) {
+                    exhausted = true;
+                } else if (meta_r[r] == 0) {                       // fenced: no extension
+                    n_ops_out[r] = 0; score_out[r] = -1; n_codes_out[r] = 0;
+                } else if (!(rflags && rflags[r])) {               // flagged reads belong to the byte kernel
+                    n = (int) lens[r];
+                    m = tlens ? (int) tlens[r] : n;
+                    loc = (int64_t) meta[r].loc;
+                    cout = codes + r * cw;
+                    t.qpl = qpl + r * wpr + BS_PADW;
+                    i = j = cnt = score = 0;
+                    sb = 0; fill = 0; widx = 0;
+                    alive = true;
+                    if (!(n > 0 && m > 0)) {                       // nothing to align: only the 'I' tail
+                        n_codes_out[r] = 0; n_ops_out[r] = n; score_out[r] = n;
+                        alive = false;
+                    }
+                }
+            }
         }
         const bool act = alive;
         const uint64_t actmask = __ballot(act);
@@ -533,14 +564,23 @@ int lrm_bs_pack_reads(const char *d_reads, uint64_t stride, const uint32_t *d_le
 }
 
 uint64_t lrm_bs_code_words(uint32_t max_len) { return (2ull * max_len + 31) / 32 + 2; }
-uint64_t lrm_bs_ckpt_words(uint64_t n) { return ((n + 63) / 64) * (uint64_t) (1024 / BS_K) * 512ull; }   // T - O <= 512
+uint64_t lrm_bs_ckpt_words(uint64_t n) {                     // T - O <= 512: at most 1024/K blocks per wavefront
+    uint64_t waves = (n + 63) / 64;
+    if (waves > LRM_BS_MAX_WAVES) waves = LRM_BS_MAX_WAVES;
+    return waves * (uint64_t) (1024 / BS_K) * 512ull;
+}
 
 int lrm_bs_launch(const LrmBsArgs *bs, const uint32_t *d_lens, const lrm_seq_meta *d_meta, const int32_t *d_meta_r,
                   const uint32_t *d_tlens, uint64_t n, int T, int O, uint8_t *d_store, uint64_t store_stride,
                   int32_t *d_n_ops, int32_t *d_score, LrmDevCounters *counters, void *stream_) {
     hipStream_t stream = (hipStream_t) stream_;
-    const uint64_t blocks = (n + 63) / 64;
-    if (blocks > 0x7fffffffull) { lrm_set_error("gact grid too large: split the batch"); return -1; }
+    uint64_t blocks = (n + 63) / 64;
+    if (blocks > LRM_BS_MAX_WAVES) blocks = LRM_BS_MAX_WAVES;              // resident wavefronts; lanes refill from the queue
+    if (const char *e = getenv("LRM_BS_WAVES")) {                          // test knob: a small grid forces refills
+        const uint64_t w = (uint64_t) atoll(e);
+        if (w >= 1 && w < blocks) blocks = w;
+    }
+    HIPCHK(hipMemsetAsync(&counters->reserved[0], 0, sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(gact_bs_kernel, dim3((uint32_t) blocks), dim3(64), 0, stream, bs->qpl, bs->wpr, d_lens, d_meta,
                        d_meta_r, bs->cpl + BS_PADW, d_tlens, bs->flags, n, T, O, bs->ckpt, bs->codes, bs->cw,
                        bs->ncodes, d_n_ops, d_score, counters);
