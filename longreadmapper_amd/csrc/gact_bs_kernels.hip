@@ -393,6 +393,10 @@ __global__ __launch_bounds__(64) void gact_bs_kernel(const uint64_t *__restrict_
         // ---- pass 2: per block recompute with decision planes, then walk through the block ----
         int a = 0, b = 0;
         bool running = act;
+        // the walk keeps at most T-O bases of either sequence; in the read's last tile it may run on to the edge
+        // but not past anti-diagonal 2(T-O) (docs/GACT_SPEC.md)
+        const int amax = last ? t.tq : min(t.tq, cap), bmax = last ? t.tt : min(t.tt, cap);
+        const int smax = last ? lim2 : 0x7fffffff;
         BsBlockRaw raw;
         bs_block_prefetch(raw, t, 0, ckw, lane);
         for (int c = 0; c < nb; ++c) {
@@ -427,36 +431,35 @@ __global__ __launch_bounds__(64) void gact_bs_kernel(const uint64_t *__restrict_
                 }
             }
             if (c + 1 < nb) bs_block_prefetch(raw, t, c + 1, ckw, lane);
-            // walk: the lane's path crosses each anti-diagonal at most once; codes 0 X, 1 =, 2 I, 3 D
-            int sw = a + b - BS_K * c;
+            // walk: the lane's path crosses each anti-diagonal at most once; codes 0 X, 1 =, 2 I, 3 D.
+            // Branch-free: every step runs in all lanes, `on` (0/1) gates its effects.
+            const int sbase = BS_K * c;
             uint64_t bw = 0;
-            int e2 = 0;
+            uint32_t e2 = 0;
 #pragma unroll
             for (int k = 0; k < BS_K; ++k) {
-                if (running && sw == k) {
-                    const uint32_t tpos = (uint32_t) (b - a + 64) >> 1;
-                    const bool up = tpos >= 32u;
-                    const uint32_t nbit = __builtin_amdgcn_ubfe(up ? N[k].hi : N[k].lo, tpos & 31u, 1u);
-                    const uint32_t gbit = __builtin_amdgcn_ubfe(up ? G[k].hi : G[k].lo, tpos & 31u, 1u);
-                    const uint32_t code = nbit * 2u + gbit;
-                    bw |= (uint64_t) code << e2;
-                    e2 += 2;
-                    score += code != 1u;
-                    a += code != 3u;
-                    b += code != 2u;
-                    sw = a + b - BS_K * c;
-                    running = a < t.tq && b < t.tt && (last ? (a + b < lim2) : (a < cap && b < cap));
-                }
+                const uint32_t on = (running && a + b == sbase + k) ? 1u : 0u;
+                const uint32_t dd = (uint32_t) (b - a + 64);
+                const bool up = dd >= 64u;
+                const uint32_t nbit = __builtin_amdgcn_ubfe(up ? N[k].hi : N[k].lo, dd >> 1, 1u);   // v_bfe takes the offset mod 32
+                const uint32_t gbit = __builtin_amdgcn_ubfe(up ? G[k].hi : G[k].lo, dd >> 1, 1u);
+                const uint32_t code = (nbit << 1) | gbit;
+                bw |= (uint64_t) (on ? code : 0u) << e2;
+                e2 += on << 1;
+                score += (int) BS_LOP3(on, nbit, gbit, TA & ~(~TB & TC));          // every column but '='
+                a += (int) BS_LOP3(on, nbit, gbit, TA & ~(TB & TC));               // every column but 'D'
+                b += (int) BS_LOP3(on, nbit, gbit, TA & ~(TB & ~TC));              // every column but 'I'
+                running = running && a < amax && b < bmax && a + b < smax;
             }
             // append the block's codes (at most 32) to the lane's code stream
             sb |= bw << fill;
-            cnt += e2 >> 1;
-            if (fill + e2 >= 64) {
+            cnt += (int) (e2 >> 1);
+            if (fill + (int) e2 >= 64) {
                 pend = sb; has_pend = true;
                 sb = (bw >> 1) >> (63 - fill);
                 fill -= 64;
             }
-            fill += e2;
+            fill += (int) e2;
         }
         if (act) {
             i += a;
