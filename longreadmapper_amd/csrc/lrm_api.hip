@@ -197,7 +197,9 @@ static int make_handle(lrm_index **out, void *d_blob, uint64_t bytes, int device
     ix->view.sa_len = h.sa_len; ix->view.con_len = h.con_len;
     for (int i = 0; i < 4; ++i) ix->view.c4[i] = h.c4[i];
     ix->view.hlen = h.hlen; ix->view.mta_len = h.mta_len;
+    ix->view.lcl = nullptr; ix->view.hl = 0; ix->view.pad_ = 0; ix->d_lcl = nullptr;
     if (lrm_bs_prepare_index(ix)) { delete ix; return -1; }
+    if (lrm_lcl_prepare_index(ix)) { lrm_bs_free_index(ix); delete ix; return -1; }
     *out = ix;
     return 0;
 }
@@ -255,6 +257,7 @@ extern "C" void lrm_index_free(lrm_index *idx) {
     if (g_cache.ws && g_cache.ws->idx == idx) { lrm_workspace_free(g_cache.ws); g_cache.ws = nullptr; }
     (void) hipSetDevice(idx->device);
     lrm_bs_free_index(idx);
+    if (idx->d_lcl) (void) hipFree(idx->d_lcl);
     if (idx->owns_blob && idx->d_blob) (void) hipFree(idx->d_blob);
     delete idx;
 }

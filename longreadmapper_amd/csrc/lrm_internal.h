@@ -74,6 +74,8 @@ struct LrmIndexView {
     uint64_t length, dollar_row, sa_len, con_len;
     uint64_t c4[4];
     int32_t hlen, mta_len;
+    const uint64_t *lcl;      // optional LONG table (hl-mers, hl > hlen), built on the device from lc + FM steps; null = unused
+    int32_t hl, pad_;
 };
 
 struct lrm_index {
@@ -83,6 +85,7 @@ struct lrm_index {
     int device;
     LrmBlobHeader hdr;
     LrmIndexView view;
+    uint64_t *d_lcl;          // long lc table (owned; may be null)
     uint64_t *d_cpl;          // planar 2-bit copy of the text for the bit-sliced GACT kernel (owned; may be null)
     int cpl_ok;               // text is pure ACGT (otherwise the byte kernels are used)
 };
@@ -160,6 +163,7 @@ int lrm_bs_launch(const LrmBsArgs *bs, const uint32_t *d_lens, const lrm_seq_met
                   const uint32_t *d_tlens, uint64_t n, int T, int O, uint8_t *d_store, uint64_t store_stride,
                   int32_t *d_n_ops, int32_t *d_score, LrmDevCounters *counters, void *stream);
 int lrm_bs_prepare_index(lrm_index *idx);
+int lrm_lcl_prepare_index(lrm_index *idx);       // seed_kernels.hip: the long seed table
 void lrm_bs_free_index(lrm_index *idx);
 
 void lrm_set_error(const char *fmt, ...);

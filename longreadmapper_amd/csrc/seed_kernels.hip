@@ -92,13 +92,31 @@ __device__ __forceinline__ void lc_lookup(const LrmIndexView &ix, uint64_t code,
 __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t win, int seed_len,
                                              uint64_t &k, uint64_t &l) {
     int left = seed_len - ix.hlen;
-    if (left >= 0) {
-        lc_lookup(ix, (win >> (2 * left)) & ((1ull << (2 * ix.hlen)) - 1ull), k, l);
-    } else {
-        k = 1;
-        l = ix.length - 1;
+    bool looked_up = false;
+    if (ix.lcl && seed_len >= ix.hl) {
+        // Long table: entry[hl-mer] = lc[hlen-mer] followed by hl - hlen backward steps, precomputed on the device
+        // (lcl_build_kernel) -- the same (k, l) the reference reaches after those steps, for one memory request
+        // instead of 1 + 2(hl - hlen).  The kernel is bound by the number of requests, and most seeds of a noisy
+        // read die inside their last hl bases.
+        const int left2 = seed_len - ix.hl;
+        const uint64_t e = ix.lcl[(win >> (2 * left2)) & ((1ull << (2 * ix.hl)) - 1ull)];
+        if ((e >> 40) != 0xFFFFFFull) {                               // (marker: interval too long for 24 bits)
+            if (e == 0) { k = 0; l = 0; return 0; }                   // dead by its hl-th base; k, l are dead values then
+            k = e & ((1ull << 40) - 1ull);
+            l = k + (e >> 40) - 1;
+            left = left2;
+            looked_up = true;
+        }
     }
-    if (k == 0 && l == 0) return 0;
+    if (!looked_up) {
+        if (left >= 0) {
+            lc_lookup(ix, (win >> (2 * left)) & ((1ull << (2 * ix.hlen)) - 1ull), k, l);
+        } else {
+            k = 1;
+            l = ix.length - 1;
+        }
+        if (k == 0 && l == 0) return 0;
+    }
     for (int i = left - 1; i >= 0; --i) {
         uint32_t c = (uint32_t) (win >> (2 * i)) & 3u;
         uint64_t ra, rb;
@@ -108,6 +126,53 @@ __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t wi
         if (k > l) break;
     }
     return k > l ? 0 : l - k + 1;
+}
+
+// long table: one lane per hl-mer; the 4^(hl-hlen) extensions of one hlen-mer are contiguous
+__global__ __launch_bounds__(256) void lcl_build_kernel(LrmIndexView ix, int hl, uint64_t *__restrict__ out,
+                                                        uint64_t code0) {
+    const uint64_t code = code0 + (uint64_t) blockIdx.x * 256 + threadIdx.x;
+    const int ext = hl - ix.hlen;
+    if (code >= (1ull << (2 * hl))) return;
+    uint64_t k, l;
+    lc_lookup(ix, code >> (2 * ext), k, l);
+    uint64_t e = 0;
+    if (!(k == 0 && l == 0)) {
+        for (int i = ext - 1; i >= 0 && k <= l; --i) {
+            const uint32_t c = (uint32_t) (code >> (2 * i)) & 3u;
+            uint64_t ra, rb;
+            occ_rank2(ix, c, k - 1, l, ra, rb);
+            k = ix.c4[c] + ra + 1;
+            l = ix.c4[c] + rb;
+        }
+        if (k <= l) {
+            const uint64_t cnt = l - k + 1;
+            e = cnt >= 0xFFFFFFull ? (0xFFFFFFull << 40) : (k | (cnt << 40));
+        }
+    }
+    out[code] = e;
+}
+
+// LRM_LC_LONG: 0 = off, 13..16 = that k-mer length, unset = automatic: 16 (32 GiB) once the occ table is far
+// beyond the caches (every backward step is then an HBM-random request: -32 % seed_search time on a chr1-sized
+// text), else 14 (2 GiB; +3 % on an E. coli-sized text, where the saved steps were cache hits anyway).
+int lrm_lcl_prepare_index(lrm_index *idx) {
+    int hl = idx->view.length >= (1ull << 26) ? 16 : 14;
+    if (const char *e = getenv("LRM_LC_LONG")) hl = atoi(e);
+    if (hl <= idx->view.hlen || hl > 16 || idx->view.length < 2) return 0;
+    uint64_t *d = nullptr;
+    const uint64_t entries = 1ull << (2 * hl);
+    if (hipMalloc(&d, entries * 8) != hipSuccess) { (void) hipGetLastError(); return 0; }     // no room: the reference's table alone
+    const uint64_t blocks = entries / 256, chunk = 1ull << 22;         // 2^30 threads per launch (grid limit 2^32)
+    for (uint64_t b0 = 0; b0 < blocks; b0 += chunk) {
+        const uint64_t nb = blocks - b0 < chunk ? blocks - b0 : chunk;
+        hipLaunchKernelGGL(lcl_build_kernel, dim3((uint32_t) nb), dim3(256), 0, 0, idx->view, hl, d, b0 * 256);
+    }
+    if (hipDeviceSynchronize() != hipSuccess) { (void) hipFree(d); lrm_set_error("long lc table build failed"); return -1; }
+    idx->d_lcl = d;
+    idx->view.lcl = d;
+    idx->view.hl = hl;
+    return 0;
 }
 
 struct __attribute__((aligned(8))) WordPair { uint64_t a, b; };
