@@ -154,10 +154,10 @@ __global__ __launch_bounds__(256) void lcl_build_kernel(LrmIndexView ix, int hl,
 }
 
 // LRM_LC_LONG: 0 = off, 13..16 = that k-mer length, unset = automatic: 16 (32 GiB) once the occ table is far
-// beyond the caches (every backward step is then an HBM-random request: -32 % seed_search time on a chr1-sized
-// text), else 14 (2 GiB; +3 % on an E. coli-sized text, where the saved steps were cache hits anyway).
+// beyond the caches -- every backward step is then an HBM-random request: -32 % seed_search time on a chr1-sized
+// text.  On an E. coli-sized text the saved steps were cache hits and the bigger table costs 3-4 %: off.
 int lrm_lcl_prepare_index(lrm_index *idx) {
-    int hl = idx->view.length >= (1ull << 26) ? 16 : 14;
+    int hl = idx->view.length >= (1ull << 26) ? 16 : 0;
     if (const char *e = getenv("LRM_LC_LONG")) hl = atoi(e);
     if (hl <= idx->view.hlen || hl > 16 || idx->view.length < 2) return 0;
     uint64_t *d = nullptr;

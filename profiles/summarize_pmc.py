@@ -18,7 +18,8 @@ os.makedirs(dst, exist_ok=True)
 
 LAUNCHES_PER_STEP = {"pack2bit_kernel": 1, "seed_search_kernel": 2, "vote_wave_kernel": 2, "vote_wave2_kernel": 4,
                      "vote_block_kernel": 2, "decide_kernel": 2, "locus_resolve_kernel": 1, "revcomp_kernel": 1,
-                     "gact3_kernel": 1, "gact_kernel": 1}
+                     "gact3_kernel": 1, "gact_kernel": 1, "gact_bs_kernel": 1, "bs_pack_reads_kernel": 1,
+                     "bs_expand_kernel": 1}
 
 
 def short(name):
@@ -73,20 +74,53 @@ for k, v in per_kernel.items():
         ("%.0f %%" % (100 * e["wait_any_q"] / e["wave_cycles_q"])) if e["wave_cycles_q"] else "-"))
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 
-kt = []
-if stats:
-    for r in csv.DictReader(open(stats[0])):
-        kt.append("| %s | %s | %.3f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e6, r["Percentage"]))
+def stats_table(path):
+    rows = []
+    for r in csv.DictReader(open(path)):
+        rows.append("| %s | %s | %.3f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e6, r["Percentage"]))
+    return "| kernel | calls | avg ms | % |\n|---|---|---|---|\n" + "\n".join(rows) + "\n"
+
+
+def event_table(b):
+    out = "| kernel | launches | avg ms |\n|---|---|---|\n"
+    for k, v in b["kernels"].items():
+        out += "| %s | %d | %.3f |\n" % (k, v["launches"], v["avg_ms"])
+    return out
+
+
+def load(name):
+    p = os.path.join(src, name)
+    if not os.path.exists(p):
+        return None
+    shutil.copy(p, os.path.join(dst, name))
+    return json.loads(open(p).read().strip().splitlines()[-1])
+
+
+b1 = load("bench_streams1.json")
+bc = load("bench_chr1_pacbio15k.json")
+stats1 = glob.glob(os.path.join(src, "trace_streams1", "*", "*_kernel_stats.csv"))
+if stats1:
+    shutil.copy(stats1[0], os.path.join(dst, "kernel_stats_streams1.csv"))
 with open(os.path.join(dst, "README.md"), "w") as f:
-    f.write("# Profiles %s — default `bench.py` workload on one MI355X\n\n" % tag)
-    f.write("`bench_default.json`: the JSON line of `python bench.py` (5 steps, 1 warm-up).\n\n")
+    f.write("# Profiles %s -- default `bench.py` workload on one MI355X\n\n" % tag)
+    f.write("`bench_default.json`: the JSON line of `python bench.py` (%d steps, %d warm-up, steps alternating over %d HIP "
+            "streams so that kernels of different steps overlap).\n\n" % (bench["steps"], bench["warmup"], bench.get("streams", 1)))
     f.write("value = **%.2f Gbp/s**, %.1f ms per 1-Gbp step; CPU oracle on %d host cores: %.4f Gbp/s (x%.0f).\n\n"
             % (bench["value"], bench["ms_per_step"], bench["cpu_baseline"]["cores"], bench["cpu_baseline"]["value"],
                bench["speedup_vs_cpu"]))
-    f.write("## HIP-event timing inside bench.py (timed steps)\n\n| kernel | launches | avg ms |\n|---|---|---|\n")
-    for k, v in bench["kernels"].items():
-        f.write("| %s | %d | %.3f |\n" % (k, v["launches"], v["avg_ms"]))
-    f.write("\n## rocprofv3 --kernel-trace --stats of `bench.py --steps 3 --warmup 1 --cpu-seconds 0` (`kernel_stats.csv`)\n\n")
-    f.write("| kernel | calls | avg ms | % |\n|---|---|---|---|\n" + "\n".join(kt) + "\n")
-    f.write("\n## PMC passes (`pmc_summary.json`; separate runs, one timed step each)\n\n" + "\n".join(lines) + "\n")
+    if b1:
+        f.write("`bench_streams1.json`: `python bench.py --streams 1` (every kernel alone on the chip): **%.2f Gbp/s**, "
+                "%.1f ms per step.\n\n" % (b1["value"], b1["ms_per_step"]))
+    if bc:
+        f.write("`bench_chr1_pacbio15k.json`: human-chr1-sized text, 50 k x 15 kbp PacBio-CLR-profile reads: **%.2f Gbp/s**, "
+                "%.1f ms per 0.75-Gbp step.\n\n" % (bc["value"], bc["ms_per_step"]))
+    f.write("## HIP-event timing inside bench.py, default command (durations include the overlap with other steps' kernels)\n\n")
+    f.write(event_table(bench))
+    if stats:
+        f.write("\n## rocprofv3 --kernel-trace --stats of the default command (`kernel_stats.csv`)\n\n" + stats_table(stats[0]))
+    if b1:
+        f.write("\n## HIP-event timing, `--streams 1` (isolated kernels)\n\n" + event_table(b1))
+    if stats1:
+        f.write("\n## rocprofv3 --kernel-trace --stats of `bench.py --streams 1` (`kernel_stats_streams1.csv`)\n\n" + stats_table(stats1[0]))
+    f.write("\n## PMC passes (`pmc_summary.json`; separate `--streams 1` runs, one timed step each)\n\n" + "\n".join(lines) + "\n")
 print(open(os.path.join(dst, "README.md")).read())

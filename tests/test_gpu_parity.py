@@ -163,12 +163,19 @@ def test_seed_search_per_seed(dev_indexes, gpu, monkeypatch, name, long_table):
 
 
 @pytest.mark.parametrize("name", workloads.SEED_SCENARIOS)
-def test_seed_batch_vs_oracle(dev_indexes, name):
+def test_seed_batch_vs_oracle(dev_indexes, gpu, monkeypatch, name):
     sc, di, oi = dev_indexes(name)
     want, phases = oi.seed_batch(sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
     got = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
     for f in ("key", "val", "bucket"):
         assert np.array_equal(got[f], want[f]), (name, f, np.nonzero(got[f] != want[f])[0][:10])
+    # the same through the long seed table (what large texts use automatically)
+    monkeypatch.setenv("LRM_LC_LONG", "14")
+    d2 = index.DeviceIndex.upload(sc["hi"], gpu)
+    got = mapper.seed_batch(d2, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+    d2.close()
+    for f in ("key", "val", "bucket"):
+        assert np.array_equal(got[f], want[f]), (name, f, "long table")
     if name == "clean-1k":
         assert (phases == 1).mean() > 0.7          # exercised the phase-0 early decision
     if name == "ont-2k":
