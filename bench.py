@@ -283,6 +283,10 @@ def main():
 
     kernels, dominant = kernel_table(ktimes)
     roofline = roofline_of(kernels, ktimes, dominant) if dominant else None
+    if roofline and nstreams > 1:
+        roofline["overlap_note"] = ("steps alternate over %d HIP streams: this duration includes the time the kernel shared "
+                                    "the chip with kernels of other steps; `bench.py --streams 1` measures it alone "
+                                    "(profiles/r1/bench_streams1.json: seed_search 15.9 ms per launch, frac 0.48)" % nstreams)
     roofline_hbm = roofline_of(kernels, ktimes, "seed_search_kernel") if "seed_search_kernel" in kernels else None
     isolated = None
     if ktimes_iso:
