@@ -50,7 +50,6 @@ static void blob_layout(uint64_t length, int hlen, int mta_len, LrmBlobHeader *h
     h->off_occ = off;       off = align256(off + h->n_blocks * sizeof(LrmOccBlock));
     h->off_lc = off;        off = align256(off + h->lc_entries * 8);
     h->off_lcx = off;       off = align256(off + LRM_LCX_MAX * 24);
-    h->off_lcb = off;       off = align256(off + (h->lc_entries + 31) / 32 * 4 + 4);
     h->off_sa = off;        off = align256(off + h->sa_len * 8);
     h->off_content = off;   off = align256(off + h->con_len + 1);
     h->off_mta = off;       off = align256(off + (uint64_t) (mta_len > 0 ? mta_len : 1) * sizeof(LrmMtaDev));
@@ -143,16 +142,6 @@ extern "C" int lrm_index_pack_blob(const lrm_dna_fmi *fmi, const lrm_lc_hash *lc
         }
         lc[code] = e;
     }
-    {
-        uint32_t *lcb = (uint32_t *) (base + h.off_lcb);
-        const uint64_t nw = (ne + 31) / 32;
-#pragma omp parallel for schedule(static)
-        for (uint64_t w = 0; w < nw; ++w) {
-            uint32_t bits = 0;
-            for (uint64_t b = 0; b < 32 && w * 32 + b < ne; ++b) bits |= (lc[w * 32 + b] != 0 ? 1u : 0u) << b;
-            lcb[w] = bits;
-        }
-    }
     if (over.size() / 3 > LRM_LCX_MAX) { lrm_set_error("too many long lchash intervals (%zu)", over.size() / 3); return -1; }
     {
         uint64_t *lcx = (uint64_t *) (base + h.off_lcx);
@@ -189,7 +178,6 @@ static int make_handle(lrm_index **out, void *d_blob, uint64_t bytes, int device
     ix->view.lc = (const uint64_t *) (b + h.off_lc);
     ix->view.lcx = (const uint64_t *) (b + h.off_lcx);
     ix->view.n_lcx = h.n_lcx;
-    ix->view.lcb = (const uint32_t *) (b + h.off_lcb);
     ix->view.sa = (const uint64_t *) (b + h.off_sa);
     ix->view.content = (const char *) (b + h.off_content);
     ix->view.mta = (const LrmMtaDev *) (b + h.off_mta);

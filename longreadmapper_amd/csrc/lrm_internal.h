@@ -56,8 +56,7 @@ struct LrmBlobHeader {
     uint64_t total_bytes;
     int32_t hlen, mta_len;
     uint64_t off_lcx, n_lcx;   // side table of {code, k, l} for intervals too long for 24 bits
-    uint64_t off_lcb;          // presence bitmap of the lc table (1 bit per hlen-mer)
-    uint64_t reserved[10];
+    uint64_t reserved[11];
 };
 static_assert(sizeof(LrmBlobHeader) == 256, "header is 256 B");
 
@@ -67,7 +66,6 @@ struct LrmIndexView {
     const uint64_t *lc;       // 8-byte entries
     const uint64_t *lcx;      // {code, k, l} triples, sorted by code
     uint64_t n_lcx;
-    const uint32_t *lcb;      // presence bitmap: 2 MiB for hlen 12, L2-resident; absent hlen-mers never touch lc[]
     const uint64_t *sa;
     const char *content;
     const LrmMtaDev *mta;

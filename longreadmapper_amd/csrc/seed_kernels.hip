@@ -6,8 +6,8 @@
 // Decomposition (MI355X-first, not the reference's per-read loop nest):
 //   pack2bit      reads (1 B/base) -> 2 bit/base stream, so a seed is ONE bit-field window
 //   seed_search   one lane per seed: lc lookup + FM backward extension        (K1, HBM gathers)
-//   vote          one wavefront per (read, phase): SA gather + LDS vote table  (K2)
-//   vote_fallback same, global-memory table, for phases that overflow the LDS table
+//   vote_wave / vote_wave2 / vote_block
+//                 one wavefront or workgroup per (read, phase): SA gather + LDS vote table, tiered by hit count (K2)
 //   decide        one lane per read: the phase state machine of alnmain.c:371-403
 //
 // The reference evaluates phases one after another and stops at the first phase whose
@@ -251,12 +251,14 @@ __global__ __launch_bounds__(256) void seed_search_debug_kernel(LrmIndexView ix,
 //
 // The vote table always lives in LDS.  Items ((read, phase) pairs) are tiered by their hit count
 // H = sum of rr, an upper bound on the distinct buckets:
-//   tier 1  H <= 192          one wavefront per item, 256 slots, 4 items per workgroup
-//   tier 2  H <= 768          one wavefront per item, 1024 slots, persistent grid over a list
-//   tier 3  any H             one workgroup per item, 3072 slots, ceil(H/limit) passes: pass p only
-//                             admits buckets with hash % passes == p, the per-pass top-2 are merged
-//                             (buckets of different passes are disjoint, so the merge is exact)
-// A tier that finds H above its limit pushes the item to the next tier's list.
+//   tier 1   H <= 192         vote_wave: one wavefront per item, 256 slots, 4 items per workgroup; stores H
+//   tier 2a  H <= 384         vote_wave2<512>: one single-wavefront workgroup per item
+//   tier 2b  H <= 768         vote_wave2<1024>
+//   tier 3   any H            vote_block: one 256-thread workgroup per item, 1280 slots, ceil(H/960) passes:
+//                             pass p only admits buckets with hash % passes == p, the per-pass top-2 are
+//                             merged (buckets of different passes are disjoint, so the merge is exact)
+// Every tier is launched over all items and keeps those whose stored H is in its range (one 4-byte read): no
+// work lists, no global atomics.
 // ----------------------------------------------------------------------------------------
 #define T1_SLOTS 256
 #define T1_LIMIT 192
