@@ -237,13 +237,112 @@ extern "C" int lrm_index_upload(lrm_index **out, const lrm_dna_fmi *fmi, const l
     return rc;
 }
 
-struct HostCache { lrm_workspace *ws; };
-static thread_local HostCache g_cache = {nullptr};
+// Per-thread state of the host-buffer entry points: the workspace, device mirrors of the caller's arrays and two
+// pinned staging chunks.  The caller's buffers are pageable (alnmain.c mallocs them): a plain hipMemcpy stages
+// them through one driver thread at a fraction of the link rate, so the copies here run chunk-wise through
+// pinned memory, the host-side half of each chunk being an OpenMP memcpy that overlaps the DMA of the previous one.
+struct DevSlot {
+    void *p = nullptr; uint64_t cap = 0;
+    int ensure(uint64_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void) hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; return -1; }
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
+};
+#define LRM_STAGE_CHUNK (32ull << 20)
+struct HostCache {
+    lrm_workspace *ws;
+    DevSlot reads, lens, best, store, nops, score, meta, mr;
+    void *pin[2]; hipStream_t copy; hipEvent_t ev[2]; int staging_ready;
+};
+static thread_local HostCache g_cache = {};
+
+static int staging_init(HostCache &c) {
+    if (c.staging_ready) return 0;
+    for (int b = 0; b < 2; ++b) {
+        if (hipHostMalloc(&c.pin[b], LRM_STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) { lrm_set_error("pinned staging allocation failed"); return -1; }
+        if (hipEventCreateWithFlags(&c.ev[b], hipEventDisableTiming) != hipSuccess) { lrm_set_error("event creation failed"); return -1; }
+    }
+    if (hipStreamCreateWithFlags(&c.copy, hipStreamNonBlocking) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
+    c.staging_ready = 1;
+    return 0;
+}
+static void staging_release(HostCache &c) {
+    if (c.staging_ready) {
+        for (int b = 0; b < 2; ++b) { (void) hipHostFree(c.pin[b]); (void) hipEventDestroy(c.ev[b]); }
+        (void) hipStreamDestroy(c.copy);
+        c.staging_ready = 0;
+    }
+    c.reads.release(); c.lens.release(); c.best.release(); c.store.release();
+    c.nops.release(); c.score.release(); c.meta.release(); c.mr.release();
+}
+#define LRM_COPY_THREADS 8        // enough to outrun the link; a library must not fan out over every core of its host
+static void par_memcpy(void *dst, const void *src, uint64_t bytes) {
+    const uint64_t piece = 1ull << 20, np = (bytes + piece - 1) / piece;
+#pragma omp parallel for schedule(static) num_threads(LRM_COPY_THREADS)
+    for (uint64_t i = 0; i < np; ++i) {
+        const uint64_t o = i * piece, l = bytes - o < piece ? bytes - o : piece;
+        memcpy((char *) dst + o, (const char *) src + o, l);
+    }
+}
+// host -> device through the pinned chunks
+static int stage_h2d(HostCache &c, void *d_dst, const void *h_src, uint64_t bytes) {
+    if (staging_init(c)) return -1;
+    uint64_t k = 0;
+    for (uint64_t o = 0; o < bytes; o += LRM_STAGE_CHUNK, ++k) {
+        const int b = (int) (k & 1);
+        const uint64_t l = bytes - o < LRM_STAGE_CHUNK ? bytes - o : LRM_STAGE_CHUNK;
+        if (k >= 2) HIPCHK(hipEventSynchronize(c.ev[b]));             // the chunk's previous DMA has drained
+        par_memcpy(c.pin[b], (const char *) h_src + o, l);
+        HIPCHK(hipMemcpyAsync((char *) d_dst + o, c.pin[b], l, hipMemcpyHostToDevice, c.copy));
+        HIPCHK(hipEventRecord(c.ev[b], c.copy));
+    }
+    HIPCHK(hipStreamSynchronize(c.copy));
+    return 0;
+}
+// device -> host, `rows` rows of `width` bytes (device pitch spitch, host pitch dpitch); rows == 1 is a flat copy
+static int stage_d2h(HostCache &c, void *h_dst, uint64_t dpitch, const void *d_src, uint64_t spitch, uint64_t width,
+                     uint64_t rows) {
+    if (staging_init(c)) return -1;
+    if (width == 0 || rows == 0) return 0;
+    const bool flat = rows == 1;
+    const uint64_t unit = flat ? LRM_STAGE_CHUNK : (LRM_STAGE_CHUNK / width ? LRM_STAGE_CHUNK / width : 0);
+    if (unit == 0) { lrm_set_error("row wider than a staging chunk"); return -1; }
+    const uint64_t total = flat ? width : rows;                      // bytes (flat) or rows
+    uint64_t k = 0, o = 0, prev_o = 0, prev_l = 0;
+    while (true) {
+        const int b = (int) (k & 1);
+        const uint64_t l = o < total ? (total - o < unit ? total - o : unit) : 0;
+        if (l) {
+            if (flat) HIPCHK(hipMemcpyAsync(c.pin[b], (const char *) d_src + o, l, hipMemcpyDeviceToHost, c.copy));
+            else HIPCHK(hipMemcpy2DAsync(c.pin[b], width, (const char *) d_src + o * spitch, spitch, width, l,
+                                         hipMemcpyDeviceToHost, c.copy));
+            HIPCHK(hipEventRecord(c.ev[b], c.copy));
+        }
+        if (prev_l) {                                                 // unpack the previous chunk while this one flies
+            const int pb = (int) ((k - 1) & 1);
+            HIPCHK(hipEventSynchronize(c.ev[pb]));
+            if (flat) par_memcpy((char *) h_dst + prev_o, c.pin[pb], prev_l);
+            else {
+#pragma omp parallel for schedule(static) num_threads(LRM_COPY_THREADS)
+                for (uint64_t r = 0; r < prev_l; ++r)
+                    memcpy((char *) h_dst + (prev_o + r) * dpitch, (const char *) c.pin[pb] + r * width, width);
+            }
+        }
+        if (l == 0) break;
+        prev_o = o; prev_l = l; o += l; ++k;
+    }
+    return 0;
+}
 
 extern "C" void lrm_index_free(lrm_index *idx) {
     if (!idx) return;
-    if (g_cache.ws && g_cache.ws->idx == idx) { lrm_workspace_free(g_cache.ws); g_cache.ws = nullptr; }
     (void) hipSetDevice(idx->device);
+    if (g_cache.ws && g_cache.ws->idx == idx) { lrm_workspace_free(g_cache.ws); g_cache.ws = nullptr; staging_release(g_cache); }
     lrm_bs_free_index(idx);
     if (idx->d_lcl) (void) hipFree(idx->d_lcl);
     if (idx->owns_blob && idx->d_blob) (void) hipFree(idx->d_blob);
@@ -456,9 +555,10 @@ extern "C" int lrm_seed_batch(lrm_index *idx, const char *reads_buf, uint64_t st
     if (stride < max_len) { lrm_set_error("stride < longest read"); return -1; }
     lrm_workspace *ws;
     if (get_cached_ws(idx, n, max_len, p.seed_len, p.thres, &ws)) return -1;
-    DevBuf d_reads, d_lens, d_best;
-    if (d_reads.alloc(n * stride) || d_lens.alloc(n * 4) || d_best.alloc(n * sizeof(lrm_entry))) { lrm_set_error("device allocation failed"); return -1; }
-    HIPCHK(hipMemcpy(d_reads.p, reads_buf, n * stride, hipMemcpyHostToDevice));
+    HostCache &hc = g_cache;
+    DevSlot &d_reads = hc.reads, &d_lens = hc.lens, &d_best = hc.best;
+    if (d_reads.ensure(n * stride) || d_lens.ensure(n * 4) || d_best.ensure(n * sizeof(lrm_entry))) { lrm_set_error("device allocation failed"); return -1; }
+    if (stage_h2d(hc, d_reads.p, reads_buf, n * stride)) return -1;
     HIPCHK(hipMemcpy(d_lens.p, lens, n * 4, hipMemcpyHostToDevice));
     if (lrm_launch_seed(idx, ws, (const char *) d_reads.p, stride, (const uint32_t *) d_lens.p, n, max_len, p.seed_len,
                         p.thres, (lrm_entry *) d_best.p, nullptr)) return -1;
@@ -485,11 +585,13 @@ extern "C" int lrm_extend_batch(lrm_index *idx, char *reads_buf, uint64_t stride
         if (get_cached_ws(idx, n, max_len, 20, 300, &ws)) return -1;   // extend only needs the counters block
     }
     const uint64_t dstride = (store_stride + 3) & ~3ull;     // the bit-sliced kernel stores CIGAR bytes four at a time
-    DevBuf d_reads, d_lens, d_best, d_store, d_nops, d_score, d_meta, d_mr;
-    if (d_reads.alloc(n * stride) || d_lens.alloc(n * 4) || d_best.alloc(n * sizeof(lrm_entry)) ||
-        d_store.alloc(n * dstride) || d_nops.alloc(n * 4) || d_score.alloc(n * 4) ||
-        d_meta.alloc(n * sizeof(lrm_seq_meta)) || d_mr.alloc(n * 4)) { lrm_set_error("device allocation failed"); return -1; }
-    HIPCHK(hipMemcpy(d_reads.p, reads_buf, n * stride, hipMemcpyHostToDevice));
+    HostCache &hc = g_cache;
+    DevSlot &d_reads = hc.reads, &d_lens = hc.lens, &d_best = hc.best, &d_store = hc.store, &d_nops = hc.nops,
+            &d_score = hc.score, &d_meta = hc.meta, &d_mr = hc.mr;
+    if (d_reads.ensure(n * stride) || d_lens.ensure(n * 4) || d_best.ensure(n * sizeof(lrm_entry)) ||
+        d_store.ensure(n * dstride) || d_nops.ensure(n * 4) || d_score.ensure(n * 4) ||
+        d_meta.ensure(n * sizeof(lrm_seq_meta)) || d_mr.ensure(n * 4)) { lrm_set_error("device allocation failed"); return -1; }
+    if (stage_h2d(hc, d_reads.p, reads_buf, n * stride)) return -1;
     HIPCHK(hipMemcpy(d_lens.p, lens, n * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_best.p, best, n * sizeof(lrm_entry), hipMemcpyHostToDevice));
     if (lrm_launch_extend(idx, ws, (char *) d_reads.p, stride, (const uint32_t *) d_lens.p, n, max_len,
@@ -497,12 +599,18 @@ extern "C" int lrm_extend_batch(lrm_index *idx, char *reads_buf, uint64_t stride
                           (int32_t *) d_score.p, (lrm_seq_meta *) d_meta.p, (int32_t *) d_mr.p, nullptr)) return -1;
     HIPCHK(hipDeviceSynchronize());
     std::vector<int32_t> nops(n);
-    HIPCHK(hipMemcpy(reads_buf, d_reads.p, n * stride, hipMemcpyDeviceToHost));      // rev-comped reads travel back
-    HIPCHK(hipMemcpy2D(store_mem, store_stride, d_store.p, dstride, store_stride, n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(nops.data(), d_nops.p, n * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(score_out, d_score.p, n * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(meta_out, d_meta.p, n * sizeof(lrm_seq_meta), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(meta_r_out, d_mr.p, n * 4, hipMemcpyDeviceToHost));
+    if (stage_d2h(hc, reads_buf, 0, d_reads.p, 0, n * stride, 1)) return -1;          // rev-comped reads travel back
+    {
+        int32_t mx = 0;                                              // only the columns some read uses cross the link
+        for (uint64_t i = 0; i < n; ++i) mx = nops[i] > mx ? nops[i] : mx;
+        uint64_t width = ((uint64_t) mx + 63) & ~63ull;
+        if (width > store_stride) width = store_stride;
+        if (stage_d2h(hc, store_mem, store_stride, d_store.p, dstride, width, n)) return -1;
+    }
     for (uint64_t i = 0; i < n; ++i) {                                              // alnmain.c:322-325, mutils.c:99-104
         cig_out[i].cigar = store_mem + i * store_stride;
         cig_out[i].n_cigar_op = nops[i];
