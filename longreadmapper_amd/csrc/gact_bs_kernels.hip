@@ -64,7 +64,10 @@ __device__ __forceinline__ void bs_pack_group(const uint8_t *src, uint64_t len, 
     }
 }
 
-// reads: word w of read r at out + r*wpr + BS_PADW + w; padding words are zeroed
+// reads: word w of read r at out + r*wpr + BS_PADW + w; padding words are zeroed.
+// One wavefront per BS_PACK_G groups of 64 bases: all its byte loads are issued before the first ballot
+// (one memory latency per 1 KiB of read instead of one per 64 bytes).
+#define BS_PACK_G 16
 __global__ __launch_bounds__(256) void bs_pack_reads_kernel(const char *__restrict__ reads, uint64_t stride,
                                                             const uint32_t *__restrict__ lens,
                                                             uint64_t *__restrict__ out, uint64_t wpr,
@@ -82,8 +85,28 @@ __global__ __launch_bounds__(256) void bs_pack_reads_kernel(const char *__restri
         for (uint64_t w = BS_PADW + 2ull * groups_per_read + lane; w < wpr; w += 64) o[w] = 0;
     }
     const uint8_t *src = reinterpret_cast<const uint8_t *>(reads) + r * stride;
-    for (uint32_t g = part; g < groups_per_read; g += waves_per_read)
-        bs_pack_group(src, len, g, lane, o + BS_PADW, flags + r);
+    const uint32_t g0 = part * BS_PACK_G;
+    uint32_t c[BS_PACK_G];
+#pragma unroll
+    for (int e = 0; e < BS_PACK_G; ++e) {
+        const uint64_t p = (uint64_t) (g0 + e) * 64 + (uint64_t) lane;
+        c[e] = p < len ? src[p] : (uint32_t) 'A';                     // bases past the end pack as A, unflagged
+    }
+    uint64_t lo = 0, hi = 0, bad = 0;                                 // lane e keeps group e's planes
+#pragma unroll
+    for (int e = 0; e < BS_PACK_G; ++e) {
+        const uint32_t code = ((c[e] >> 1) ^ (c[e] >> 2)) & 3u;
+        const uint64_t l_ = __ballot(code & 1u), h_ = __ballot(code >> 1);
+        const uint64_t b_ = __ballot(!(c[e] == 'A' || c[e] == 'C' || c[e] == 'G' || c[e] == 'T'));
+        if (lane == e) { lo = l_; hi = h_; }
+        bad |= b_;
+    }
+    if (lane < BS_PACK_G && g0 + (uint32_t) lane < groups_per_read) {
+        uint64_t *w = o + BS_PADW + 2ull * (g0 + (uint32_t) lane);
+        w[0] = (lo & 0xffffffffull) | (hi << 32);
+        w[1] = (lo >> 32) | (hi & 0xffffffff00000000ull);
+    }
+    if (bad && lane == 0) atomicOr(flags + r, 1u);
 }
 
 // reference text: one wavefront per 64 KiB
@@ -470,7 +493,17 @@ __global__ __launch_bounds__(64) void gact_bs_kernel(const uint64_t *__restrict_
     if (lane == 0 && tiles) atomicAdd(&counters->gact_tiles, (unsigned long long) tiles);
 }
 
-// codes -> CIGAR bytes ('=' 'X' 'I' 'D', one per alignment column): one thread per four columns
+// codes -> CIGAR bytes ('=' 'X' 'I' 'D', one per alignment column): one thread per 16 columns (one 16-byte store
+// when the row is 16-byte aligned, four 4-byte stores otherwise)
+__device__ __forceinline__ uint32_t bs_ops4(uint32_t c8, int o, int nc) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t op = o + e < nc ? __builtin_amdgcn_ubfe(0x44493d58u, ((c8 >> (2 * e)) & 3u) * 8u, 8u) : (uint32_t) 'I';
+        w |= op << (8 * e);
+    }
+    return w;
+}
 __global__ __launch_bounds__(256) void bs_expand_kernel(const uint64_t *__restrict__ codes, uint64_t cw,
                                                         const int32_t *__restrict__ n_codes,
                                                         const int32_t *__restrict__ n_ops,
@@ -482,18 +515,23 @@ __global__ __launch_bounds__(256) void bs_expand_kernel(const uint64_t *__restri
     if (r >= n_reads) return;
     if (meta_r[r] == 0 || (rflags && rflags[r])) return;         // fenced, or written by the byte kernel
     const int no = n_ops[r], nc = n_codes[r];
-    const int o = (int) ((blockIdx.x % blocks_per_read) * 256 + threadIdx.x) * 4;
+    const int o = (int) ((blockIdx.x % blocks_per_read) * 256 + threadIdx.x) * 16;
     if (o >= no) return;
-    const uint32_t c8 = (uint32_t) (codes[r * cw + (uint64_t) (o >> 5)] >> ((o & 31) * 2)) & 0xffu;
-    uint32_t w = 0;
+    const uint32_t c32 = (uint32_t) (codes[r * cw + (uint64_t) (o >> 5)] >> ((o & 31) * 2));
+    uint32_t w[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const uint32_t op = o + e < nc ? __builtin_amdgcn_ubfe(0x44493d58u, ((c8 >> (2 * e)) & 3u) * 8u, 8u) : (uint32_t) 'I';
-        w |= op << (8 * e);
-    }
+    for (int q = 0; q < 4; ++q) w[q] = bs_ops4((c32 >> (8 * q)) & 0xffu, o + 4 * q, nc);
     uint8_t *out = store + r * store_stride + o;
-    if (o + 4 <= no) *reinterpret_cast<uint32_t *>(out) = w;
-    else for (int e = 0; o + e < no; ++e) out[e] = (uint8_t) (w >> (8 * e));
+    if (o + 16 <= no && (((uintptr_t) out) & 15u) == 0) {
+        *reinterpret_cast<uint4 *>(out) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oq = o + 4 * q;
+            if (oq + 4 <= no) *reinterpret_cast<uint32_t *>(out + 4 * q) = w[q];
+            else for (int e = 0; oq + e < no; ++e) out[4 * q + e] = (uint8_t) (w[q] >> (8 * e));
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------------------
@@ -556,7 +594,7 @@ int lrm_bs_pack_reads(const char *d_reads, uint64_t stride, const uint32_t *d_le
                       uint64_t *d_qpl, uint64_t wpr, uint32_t *d_flags, void *stream_) {
     hipStream_t stream = (hipStream_t) stream_;
     const uint32_t gpr = (max_len + 63) / 64;
-    uint32_t wv = (gpr + 15) / 16;                     // ~16 groups (1 KiB of read) per wavefront
+    uint32_t wv = (gpr + BS_PACK_G - 1) / BS_PACK_G;   // 16 groups (1 KiB of read) per wavefront
     if (wv == 0) wv = 1;
     const uint64_t waves = n * wv;
     if ((waves + 3) / 4 > 0x7fffffffull) { lrm_set_error("planar pack grid too large: split the batch"); return -1; }
@@ -587,7 +625,7 @@ int lrm_bs_launch(const LrmBsArgs *bs, const uint32_t *d_lens, const lrm_seq_met
     hipLaunchKernelGGL(gact_bs_kernel, dim3((uint32_t) blocks), dim3(64), 0, stream, bs->qpl, bs->wpr, d_lens, d_meta,
                        d_meta_r, bs->cpl + BS_PADW, d_tlens, bs->flags, n, T, O, bs->ckpt, bs->codes, bs->cw,
                        bs->ncodes, d_n_ops, d_score, counters);
-    const uint32_t bpr = (uint32_t) ((bs->cw * 32 + 1023) / 1024);
+    const uint32_t bpr = (uint32_t) ((bs->cw * 32 + 4095) / 4096);          // 256 threads x 16 columns per block
     if (n * bpr > 0x7fffffffull) { lrm_set_error("expand grid too large: split the batch"); return -1; }
     hipLaunchKernelGGL(bs_expand_kernel, dim3((uint32_t) (n * bpr)), dim3(256), 0, stream, bs->codes, bs->cw, bs->ncodes,
                        d_n_ops, bs->flags, d_meta_r, n, bpr, d_store, store_stride);

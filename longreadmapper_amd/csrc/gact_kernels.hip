@@ -68,6 +68,15 @@ __device__ __forceinline__ char comp_base(char c) {           // alnmain.c:31-52
     }
 }
 
+__device__ __forceinline__ uint32_t revcomp4(uint32_t w) {       // 4 bases: reversed and complemented
+    uint32_t o = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o |= (uint32_t) (uint8_t) comp_base((char) (w >> (8 * (3 - e)))) << (8 * e);
+    return o;
+}
+
+// One thread per 4 bases of the front half and their 4 mirror bases (two 4-byte loads, two 4-byte stores; rows
+// start at any byte, the hardware handles the unaligned dwords); the < 8 bases left in the middle go bytewise.
 __global__ __launch_bounds__(256) void revcomp_kernel(char *__restrict__ reads, uint64_t stride,
                                                       const uint32_t *__restrict__ lens,
                                                       const lrm_seq_meta *__restrict__ meta,
@@ -77,17 +86,29 @@ __global__ __launch_bounds__(256) void revcomp_kernel(char *__restrict__ reads, 
     uint32_t chunk = blockIdx.x % chunks_per_read;
     if (read >= n) return;
     if (!meta_r[read] || meta[read].strand != 1) return;       // alnmain.c:433
-    uint32_t len = lens[read];
-    uint32_t x = chunk * 256 + threadIdx.x;
-    uint32_t half = (len + 1) / 2;
-    if (x >= half) return;
+    const uint32_t len = lens[read];
+    const uint32_t t = chunk * 256 + threadIdx.x;
+    const uint32_t nfull = len / 8;
     char *r = reads + read * stride;
-    uint32_t y = len - 1 - x;
-    char cx = comp_base(r[x]);
-    if (x == y) { r[x] = cx; return; }
-    char cy = comp_base(r[y]);
-    r[x] = cy;
-    r[y] = cx;
+    if (t < nfull) {
+        uint32_t a, b;
+        __builtin_memcpy(&a, r + 4 * t, 4);
+        __builtin_memcpy(&b, r + (len - 4 - 4 * t), 4);
+        const uint32_t fa = revcomp4(b), fb = revcomp4(a);
+        __builtin_memcpy(r + 4 * t, &fa, 4);
+        __builtin_memcpy(r + (len - 4 - 4 * t), &fb, 4);
+    } else if (t == nfull) {
+        uint32_t x = 4 * nfull, y = len - 4 * nfull;             // [x, y): len % 8 bases
+        while (x < y) {
+            --y;
+            const char cx = comp_base(r[x]);
+            if (x == y) { r[x] = cx; break; }
+            const char cy = comp_base(r[y]);
+            r[x] = cy;
+            r[y] = cx;
+            ++x;
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------------------
@@ -896,8 +917,7 @@ int lrm_launch_extend(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint64_t
                        idx->view, d_best, d_lens, n, d_meta, d_meta_r);
     lrm_time_end(ws, stream);
     {
-        uint32_t cpr = ((max_len + 1) / 2 + 255) / 256;
-        if (cpr == 0) cpr = 1;
+        uint32_t cpr = (max_len / 8 + 1 + 255) / 256;
         uint64_t blocks = n * cpr;
         if (blocks > 0x7fffffffull) { lrm_set_error("revcomp grid too large: split the batch"); return -1; }
         lrm_time_begin(ws, LRM_K_REVCOMP, stream);
