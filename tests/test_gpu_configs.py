@@ -67,6 +67,27 @@ def test_ultralong_100k_gact_sweep(ref3, T, O, W):
     _compare(di, oi, r["reads"], r["lens"], (T, O, W))
 
 
+@pytest.mark.parametrize("T,O", [(256, 64), (320, 32), (320, 120), (512, 120)])
+def test_ultralong_100k_bitsliced(ref3, monkeypatch, T, O):
+    """The W = 128 points of the config-4 sweep through the lane-per-read kernel (500 tiles per read), reads of
+    100 kbp next to short ones so that lanes finish at very different times."""
+    monkeypatch.setenv("LRM_GACT_IMPL", "4")
+    seqs, hi, di, oi = ref3
+    r = synth.reads(seqs, 6, 100_000, synth.ONT, seed=17)
+    lens = r["lens"].copy()
+    lens[1], lens[4] = 7_000, 333
+    _compare(di, oi, r["reads"], lens, (T, O, 128))
+
+
+def test_pacbio_and_multiseq_bitsliced(ref3, monkeypatch):
+    monkeypatch.setenv("LRM_GACT_IMPL", "4")
+    seqs, hi, di, oi = ref3
+    r = synth.reads(seqs, 48, 15_000, synth.PACBIO_CLR, seed=13)
+    _compare(di, oi, r["reads"], r["lens"], (320, 120, 128))
+    r = synth.reads(seqs, 64, 10_000, synth.ONT, seed=11)
+    _compare(di, oi, r["reads"], r["lens"], (320, 120, 128))
+
+
 def test_largest_tile_and_band(ref3):
     """T = 512, O = 0, W = 1024: the largest traceback the kernel supports (134 KiB of LDS per wavefront)."""
     seqs, hi, di, oi = ref3
