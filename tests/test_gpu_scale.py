@@ -82,3 +82,28 @@ def test_oracle_spot_check(world):
     for n, i in enumerate(idx):
         k = int(want["n_ops"][n])
         assert bytes(want["ops"][n, :k]) == bytes(world["ext"]["ops"][i, :k])
+
+
+def test_bitsliced_and_score_kernels_agree_at_batch_scale(world, monkeypatch):
+    """20 k reads: above the automatic switch to the lane-per-read bit-sliced kernel.  Its CIGARs must equal the
+    score kernel's for every read (two independent formulations of docs/GACT_SPEC.md), and the oracle's on a few."""
+    di = world["di"]
+    r = synth.reads([world["ref"]], 20_000, LR, synth.ONT, seed=23)
+    best = mapper.seed_batch(di, r["reads"], r["lens"])
+    ra = r["reads"].copy()
+    a = mapper.extend_batch(di, ra, r["lens"], best)                 # automatic: bit-sliced at this size
+    monkeypatch.setenv("LRM_GACT_IMPL", "3")
+    rb = r["reads"].copy()
+    b = mapper.extend_batch(di, rb, r["lens"], best)
+    assert np.array_equal(ra, rb)
+    assert np.array_equal(a["score"], b["score"]) and np.array_equal(a["n_ops"], b["n_ops"])
+    cols = np.arange(a["ops"].shape[1])[None, :] < a["n_ops"][:, None]
+    assert np.array_equal(np.where(cols, a["ops"], 0), np.where(cols, b["ops"], 0))
+    oi = orc.OracleIndex.from_host_index(world["hi"])
+    idx = np.arange(0, 20_000, 2500)
+    reads = np.ascontiguousarray(r["reads"][idx]).copy()
+    want = oi.extend_batch(reads, r["lens"][idx], best[idx], nthreads=8)
+    assert np.array_equal(want["score"], a["score"][idx])
+    for n, i in enumerate(idx):
+        k = int(want["n_ops"][n])
+        assert bytes(want["ops"][n, :k]) == bytes(a["ops"][i, :k])
