@@ -205,7 +205,9 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
     // seeds overlap, so they share their fate (a sequencing error kills ~20 consecutive seeds, a clean
     // stretch lets all of them run the full backward extension): wavefronts diverge little.
     // Measured alternatives that lost: q fastest (coalesced record stores, but every wavefront mixes
-    // dead and live lanes: +26 %), two seeds per lane (+26 %), lane refill from a work chunk (+13 %).
+    // dead and live lanes: +26 %), two seeds per lane (+26 %), lane refill from a work chunk (+13 %),
+    // packing the survivors of the table lookup into the workgroup's first wavefronts through LDS (+8 %):
+    // the kernel is bound by the rate of memory requests, not by idle lanes or wavefront slots.
     uint32_t item = chunk * 256 + threadIdx.x;
     uint32_t q = item / (uint32_t) np;
     int iter = phase_lo + (int) (item % (uint32_t) np);
