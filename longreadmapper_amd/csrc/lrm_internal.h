@@ -18,9 +18,6 @@
 //                  stays resident in the 256 MiB Infinity Cache.  Intervals of >= 2^24-1 rows are
 //                  marked 0xFFFFFF and resolved through a small sorted side table [lcx].
 //                  (reference order: first base most significant, lchash.c:36-49; the packer permutes.)
-//   [lc bitmap]    1 bit per hlen-mer (2 MiB for hlen 12): ~40 % of the seeds of a noisy read carry an
-//                  absent hlen-mer; they are answered from this L2-resident bitmap instead of a
-//                  random 64-byte fetch into the 128 MiB table.
 //   [sa]           u64 per row (values of sa_access, fmidx.c:18-33)
 //   [content]      the .cat text, 1 byte per base (GACT target side)
 //   [mta]          {u64 offset, u64 seq_len} per sequence (accaln.h:67-71 without names)
