@@ -546,13 +546,19 @@ static uint32_t max_of(const uint32_t *lens, uint64_t n) {
     return m;
 }
 
-extern "C" int lrm_seed_batch(lrm_index *idx, const char *reads_buf, uint64_t stride, const uint32_t *lens,
-                              uint64_t n, lrm_params p, lrm_entry *best_out) {
-    if (!idx || !reads_buf || !lens || !best_out) { lrm_set_error("null argument"); return -1; }
-    if (n == 0) return 0;
-    if (require_device(idx->device)) return -1;
-    uint32_t max_len = max_of(lens, n);
-    if (stride < max_len) { lrm_set_error("stride < longest read"); return -1; }
+// Reads per device pass of the host-buffer entry points: the per-batch scratch is ~13 bytes per read base (seed
+// records 8, op bytes 2, codes, packed copies), so very large caller batches (the reference's sweeps use up to
+// 1 M reads, gen-sbatch-scripts.py:74) go through the device in slices of ~32 GB of scratch.  Results do not
+// depend on the slicing: there is no cross-read state.
+static uint64_t host_slice_reads(uint32_t max_len) {
+    if (const char *e = getenv("LRM_HOST_SLICE")) { const long long v = atoll(e); if (v >= 1) return (uint64_t) v; }   // test knob
+    const uint64_t per_read = 13ull * (max_len ? max_len : 1) + 4096;
+    uint64_t r = (32ull << 30) / per_read;
+    return r < 16384 ? 16384 : r;
+}
+
+static int seed_slice(lrm_index *idx, const char *reads_buf, uint64_t stride, const uint32_t *lens, uint64_t n,
+                      uint32_t max_len, lrm_params p, lrm_entry *best_out) {
     lrm_workspace *ws;
     if (get_cached_ws(idx, n, max_len, p.seed_len, p.thres, &ws)) return -1;
     HostCache &hc = g_cache;
@@ -569,17 +575,25 @@ extern "C" int lrm_seed_batch(lrm_index *idx, const char *reads_buf, uint64_t st
     return 0;
 }
 
-extern "C" int lrm_extend_batch(lrm_index *idx, char *reads_buf, uint64_t stride, const uint32_t *lens, uint64_t n,
-                                const lrm_entry *best, lrm_gact_params gp, lrm_cigar *cig_out, uint8_t *store_mem,
-                                uint64_t store_stride, int *score_out, lrm_seq_meta *meta_out, int *meta_r_out) {
-    if (!idx || !reads_buf || !lens || !best || !cig_out || !store_mem || !score_out || !meta_out || !meta_r_out) {
-        lrm_set_error("null argument");
-        return -1;
-    }
+extern "C" int lrm_seed_batch(lrm_index *idx, const char *reads_buf, uint64_t stride, const uint32_t *lens,
+                              uint64_t n, lrm_params p, lrm_entry *best_out) {
+    if (!idx || !reads_buf || !lens || !best_out) { lrm_set_error("null argument"); return -1; }
     if (n == 0) return 0;
     if (require_device(idx->device)) return -1;
-    uint32_t max_len = max_of(lens, n);
+    const uint32_t max_len = max_of(lens, n);
     if (stride < max_len) { lrm_set_error("stride < longest read"); return -1; }
+    const uint64_t slice = host_slice_reads(max_len);
+    for (uint64_t o = 0; o < n; o += slice) {
+        const uint64_t m = n - o < slice ? n - o : slice;
+        if (seed_slice(idx, reads_buf + o * stride, stride, lens + o, m, max_len, p, best_out + o)) return -1;
+    }
+    return 0;
+}
+
+static int extend_slice(lrm_index *idx, char *reads_buf, uint64_t stride, const uint32_t *lens, uint64_t n,
+                        uint32_t max_len, const lrm_entry *best, lrm_gact_params gp, lrm_cigar *cig_out,
+                        uint8_t *store_mem, uint64_t store_stride, int *score_out, lrm_seq_meta *meta_out,
+                        int *meta_r_out) {
     lrm_workspace *ws = g_cache.ws;
     if (!ws || ws->idx != idx) {
         if (get_cached_ws(idx, n, max_len, 20, 300, &ws)) return -1;   // extend only needs the counters block
@@ -615,6 +629,26 @@ extern "C" int lrm_extend_batch(lrm_index *idx, char *reads_buf, uint64_t stride
         cig_out[i].cigar = store_mem + i * store_stride;
         cig_out[i].n_cigar_op = nops[i];
         cig_out[i].score = score_out[i];
+    }
+    return 0;
+}
+
+extern "C" int lrm_extend_batch(lrm_index *idx, char *reads_buf, uint64_t stride, const uint32_t *lens, uint64_t n,
+                                const lrm_entry *best, lrm_gact_params gp, lrm_cigar *cig_out, uint8_t *store_mem,
+                                uint64_t store_stride, int *score_out, lrm_seq_meta *meta_out, int *meta_r_out) {
+    if (!idx || !reads_buf || !lens || !best || !cig_out || !store_mem || !score_out || !meta_out || !meta_r_out) {
+        lrm_set_error("null argument");
+        return -1;
+    }
+    if (n == 0) return 0;
+    if (require_device(idx->device)) return -1;
+    const uint32_t max_len = max_of(lens, n);
+    if (stride < max_len) { lrm_set_error("stride < longest read"); return -1; }
+    const uint64_t slice = host_slice_reads(max_len);
+    for (uint64_t o = 0; o < n; o += slice) {
+        const uint64_t m = n - o < slice ? n - o : slice;
+        if (extend_slice(idx, reads_buf + o * stride, stride, lens + o, m, max_len, best + o, gp, cig_out + o,
+                         store_mem + o * store_stride, store_stride, score_out + o, meta_out + o, meta_r_out + o)) return -1;
     }
     return 0;
 }

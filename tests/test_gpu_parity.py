@@ -324,6 +324,26 @@ def test_bitsliced_lane_refill(dev_indexes, monkeypatch, waves):
     assert np.array_equal(r_gpu, r_cpu)
 
 
+def test_host_batches_are_sliced_without_changing_results(dev_indexes, monkeypatch):
+    """Caller batches above ~32 GB of device scratch go through the device in slices (LRM_HOST_SLICE forces 7 reads
+    per slice here): same best[], scores, ops, rev-comped reads as in one pass."""
+    sc, di, oi = dev_indexes("ont-2k")
+    best = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+    r1 = sc["reads"].copy()
+    e1 = mapper.extend_batch(di, r1, sc["lens"], best)
+    monkeypatch.setenv("LRM_HOST_SLICE", "7")
+    best2 = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+    r2 = sc["reads"].copy()
+    e2 = mapper.extend_batch(di, r2, sc["lens"], best2)
+    assert np.array_equal(best, best2) and np.array_equal(r1, r2)
+    assert np.array_equal(e1["score"], e2["score"]) and np.array_equal(e1["n_ops"], e2["n_ops"])
+    for i in range(len(best)):
+        k = int(e1["n_ops"][i])
+        assert bytes(e1["ops"][i, :k]) == bytes(e2["ops"][i, :k]), i
+    for f in ("loc", "off", "seq_id", "strand"):
+        assert np.array_equal(e1["meta"][f], e2["meta"][f])
+
+
 def test_blob_roundtrip_and_adopt(dev_indexes, gpu):
     """The image broadcast path: pack on the host, move as bytes, adopt on the device."""
     import torch
