@@ -100,7 +100,7 @@ struct LrmDevCounters {
     unsigned long long pad;
 };
 
-enum LrmKernelId { LRM_K_PACK2BIT = 0, LRM_K_SEED_SEARCH, LRM_K_VOTE, LRM_K_VOTE_FALLBACK, LRM_K_DECIDE,
+enum LrmKernelId { LRM_K_PACK2BIT = 0, LRM_K_SEED_SEARCH, LRM_K_VOTE, LRM_K_VOTE_WAVE2, LRM_K_DECIDE,
                    LRM_K_LOCUS, LRM_K_REVCOMP, LRM_K_GACT, LRM_K_VOTE_BLOCK, LRM_K_PACK_PLANAR, LRM_K_GACT_BS,
                    LRM_K_COUNT };
 #define LRM_MAX_TIMED 4096

@@ -369,8 +369,6 @@ __device__ __forceinline__ bool vote_admit(const VoteTable &t, uint64_t key, uin
 
 // Repeat seeds (rr > 4): the hits of one seed are a contiguous run of SA rows, read by the whole
 // wavefront at once; the first 64 rows of up to four such seeds are in flight together.
-struct BigList { uint64_t *k; uint32_t *q; uint32_t *incl; };     // (reserved) per-wavefront scratch
-#define BIG_CAP 64
 
 __device__ __forceinline__ bool vote_big_seeds(const LrmIndexView &ix, const VoteTable &t, uint32_t rr, uint64_t k,
                                                uint32_t q0, uint32_t iter, uint32_t P, uint32_t tbits, int lane,
@@ -421,7 +419,7 @@ __device__ __forceinline__ bool vote_small_hits(const VoteTable &t, uint32_t rr,
     return ok;
 }
 
-__device__ __forceinline__ bool vote_chunk(const LrmIndexView &ix, const VoteTable &t, const BigList &bl, uint64_t e,
+__device__ __forceinline__ bool vote_chunk(const LrmIndexView &ix, const VoteTable &t, uint64_t e,
                                            uint32_t q, uint32_t iter, uint32_t P, uint32_t tbits, int lane,
                                            uint32_t passes, uint32_t pass) {
     const uint32_t rr = (uint32_t) (e >> 40);
@@ -438,7 +436,7 @@ template <int SLOTS>
 __device__ __forceinline__ void vote_item_wave(const LrmIndexView &ix, const uint64_t *__restrict__ r, uint32_t cnt,
                                                uint32_t iter, uint32_t P, uint32_t H, uint32_t tbits, int lane,
                                                uint64_t *tb_bucket, uint32_t *tb_count, uint32_t *tb_first,
-                                               uint32_t *tb_minlow, const BigList &bl, LrmPhaseRes *out,
+                                               uint32_t *tb_minlow, LrmPhaseRes *out,
                                                uint64_t (&e0)[VOTE_BATCH]) {
     VoteTable t = {tb_bucket, tb_count, tb_first, tb_minlow, 0};
     {   // clear / scan only as much of the table as this item can fill (<= 75 % load)
@@ -546,9 +544,8 @@ __global__ __launch_bounds__(256) void vote_wave_kernel(LrmIndexView ix, const u
         return;
     }
     if (H > limit) return;
-    const BigList bl = {nullptr, nullptr, nullptr};
     vote_item_wave<T1_SLOTS>(ix, r, cnt, (uint32_t) iter, (uint32_t) P, H, tbits, lane, s_bucket[wave], s_count[wave],
-                             s_first[wave], s_minlow[wave], bl, &phase_res[id], e0);
+                             s_first[wave], s_minlow[wave], &phase_res[id], e0);
 }
 
 // tier 2: grid over every item as well, ONE wavefront per workgroup (a wavefront that finds its
@@ -581,9 +578,8 @@ __global__ __launch_bounds__(64) void vote_wave2_kernel(LrmIndexView ix, const u
     const uint64_t *r = rec + id * cap_q;
     uint64_t e0[VOTE_BATCH];
     load_records(r, cnt, 0, lane, e0);
-    const BigList bl = {nullptr, nullptr, nullptr};
     vote_item_wave<SLOTS>(ix, r, cnt, (uint32_t) iter, (uint32_t) P, H, tbits, lane, tb_bucket, tb_count, tb_first,
-                          tb_minlow, bl, &phase_res[id], e0);
+                          tb_minlow, &phase_res[id], e0);
 }
 
 // ---- tier 3: one 256-thread workgroup per item; a workgroup owns T3_GROUP consecutive items and
@@ -642,8 +638,7 @@ __global__ __launch_bounds__(256) void vote_block_kernel(LrmIndexView ix, const 
             for (uint32_t q0 = 0; q0 < cnt; q0 += 256) {      // each wavefront votes its own 64 seeds
                 const uint32_t qw = q0 + (uint32_t) wave * 64, q = qw + lane;
                 const uint64_t e = q < cnt ? r[q] : 0ull;
-                const BigList bl = {nullptr, nullptr, nullptr};
-                ok &= vote_chunk(ix, t, bl, e, q, iter, (uint32_t) P, tbits, lane, passes, pass);
+                            ok &= vote_chunk(ix, t, e, q, iter, (uint32_t) P, tbits, lane, passes, pass);
             }
             if (!ok) atomicOr(err_flags, 1ull);
             __syncthreads();
@@ -812,7 +807,7 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
                            d_lens, dec, n, (int) seed_len, lo, hi, cap_q, tbits, (uint32_t) T1_LIMIT, ws->d_phase,
                            ws->d_hcount);
         lrm_time_end(ws, stream);
-        lrm_time_begin(ws, LRM_K_VOTE_FALLBACK, stream);
+        lrm_time_begin(ws, LRM_K_VOTE_WAVE2, stream);
         {
             size_t sh3 = (size_t) T3_SLOTS * 20;
             if (items > 0x7fffffffull) { lrm_set_error("vote grid too large: split the batch"); return -1; }
