@@ -32,6 +32,19 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota (a GPU box hands a job a
+    share of its host, e.g. 16 of 256 hardware threads; more OpenMP threads than that only get throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def load_pmc_summary(args, n, Lr):
     """HBM traffic per kernel from the committed rocprofv3 PMC passes of THIS workload (profiles/rNN/
     pmc_summary.json, made by profiles/collect.sh + summarize_pmc.py); None for any other workload."""
@@ -193,7 +206,7 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
     oi = orc.OracleIndex.from_host_index(hi)
-    cores = min(orc.lib.orc_max_threads(), os.cpu_count() or 1)
+    cores = min(orc.lib.orc_max_threads(), usable_cpus())
     cpu = None
     per_base = None
     sample_n = min(n, 4 * cores)
