@@ -1,5 +1,5 @@
 // SPDX-License-Identifier: MIT
-// Bit-sliced GACT for the default band (W = 128): ONE LANE PER READ, 64 lattice points per 64-bit word.
+// Bit-sliced GACT for bands of up to 128 diagonals (the default): ONE LANE PER READ, 64 lattice points per word.
 // Replaces the reference's per-read simple_gact call (mutils.c:97-103) for large batches; bit-exact
 // against oracle/lrm_oracle.c:orc_gact (docs/GACT_SPEC.md).  tests/models/gact_bitslice_model.c is the
 // CPU model of exactly this sequence of operations.
@@ -170,6 +170,8 @@ struct BsPl { uint32_t lo, hi; };                    // one bit-plane of an anti
 struct BsStream {
     BsWord q0, q1, q2, d0, d1, d2;     // three consecutive stream words each
     BsPl Qlo, Qhi, Qs, Dlo, Dhi, Ds;
+    BsPl bandE, bandO;                 // lattice points inside the band on even / odd anti-diagonals (all ones for W = 128)
+    bool narrow;                       // W < 128: every step takes the masked (BOUND) form
     int qnext, dnext;                  // wave-uniform: a of bit 0 of the next query word / b of the next (lower) text word
 };
 
@@ -201,6 +203,7 @@ __device__ __forceinline__ void bs_stream_init(BsStream &st, const BsTile &t, in
 }
 // does any lane hold a free-exit point in its current stream words?  (wave-uniform)
 __device__ __forceinline__ bool bs_any_sentinel(const BsStream &st) {
+    if (st.narrow) return true;
     return __ballot((st.q0.sent | st.q1.sent | st.q2.sent | st.d0.sent | st.d1.sent | st.d2.sent) != 0u) != 0ull;
 }
 
@@ -214,7 +217,7 @@ enum : uint32_t { TA = 0xF0u, TB = 0xCCu, TC = 0xAAu };
 // one 32-bit half of an anti-diagonal: u = H of the lower neighbour, w = V of the upper one
 template <bool BOUND, bool TRACK>
 __device__ __forceinline__ void bs_half(uint32_t u1, uint32_t u0, uint32_t w1, uint32_t w0, uint32_t ql, uint32_t qh,
-                                        uint32_t dl, uint32_t dh, uint32_t bm, uint32_t &V1, uint32_t &V0,
+                                        uint32_t dl, uint32_t dh, uint32_t bm, uint32_t band, uint32_t &V1, uint32_t &V0,
                                         uint32_t &H1, uint32_t &H0, uint32_t &N, uint32_t &G) {
     const uint32_t e1 = ql ^ dl;
     const uint32_t m = BS_LOP3(e1, qh, dh, ~TA & ~(TB ^ TC));              // bases equal
@@ -232,9 +235,10 @@ __device__ __forceinline__ void bs_half(uint32_t u1, uint32_t u0, uint32_t w1, u
     uint32_t v0 = BS_LOP3(x, nd, u0, TA | (~(TB | TC) & 0xFFu));
     const uint32_t xx = BS_LOP3(nd, lt, d0, TA & ~TB & TC);
     uint32_t h0 = BS_LOP3(xx, nd, w0, TA | (~(TB | TC) & 0xFFu));
-    if (BOUND) {                                                           // free-exit points: V = H = 0 (code 1)
-        v1 = BS_LOP3(v1, bm, bm, TA & ~TB);  v0 |= bm;
-        h1 = BS_LOP3(h1, bm, bm, TA & ~TB);  h0 |= bm;
+    if (BOUND) {                 // free-exit points: V = H = 0 (code 1); lattice points outside a band narrower
+                                 // than the 128 diagonals of the planes: code 0 (-1), the value that never wins
+        v1 = BS_LOP3(v1, bm, band, TA & ~TB & TC);  v0 = BS_LOP3(v0, bm, band, (TA | TB) & TC);
+        h1 = BS_LOP3(h1, bm, band, TA & ~TB & TC);  h0 = BS_LOP3(h0, bm, band, (TA | TB) & TC);
     }
     V1 = v1; V0 = v0; H1 = h1; H0 = h0;
     if (TRACK) { N = nd; G = BS_LOP3(nd, lt, m, (TA & TB) | (~TA & TC)); }   // G: deletion if N, else MATCH
@@ -254,10 +258,15 @@ __device__ __forceinline__ void bs_step(BsState &x, const BsStream &st, BsPl &N,
         w0.lo = bs_alignbit(x.V0.hi, x.V0.lo, 1); w0.hi = x.V0.hi >> 1;
     }
     const uint32_t bl = BOUND ? (st.Qs.lo | st.Ds.lo) : 0u, bh = BOUND ? (st.Qs.hi | st.Ds.hi) : 0u;
-    bs_half<BOUND, TRACK>(u1.lo, u0.lo, w1.lo, w0.lo, st.Qlo.lo, st.Qhi.lo, st.Dlo.lo, st.Dhi.lo, bl,
+    const BsPl &band = ODD ? st.bandO : st.bandE;
+    bs_half<BOUND, TRACK>(u1.lo, u0.lo, w1.lo, w0.lo, st.Qlo.lo, st.Qhi.lo, st.Dlo.lo, st.Dhi.lo, bl, band.lo,
                           x.V1.lo, x.V0.lo, x.H1.lo, x.H0.lo, N.lo, G.lo);
-    bs_half<BOUND, TRACK>(u1.hi, u0.hi, w1.hi, w0.hi, st.Qlo.hi, st.Qhi.hi, st.Dlo.hi, st.Dhi.hi, bh,
+    bs_half<BOUND, TRACK>(u1.hi, u0.hi, w1.hi, w0.hi, st.Qlo.hi, st.Qhi.hi, st.Dlo.hi, st.Dhi.hi, bh, band.hi,
                           x.V1.hi, x.V0.hi, x.H1.hi, x.H0.hi, N.hi, G.hi);
+}
+
+__device__ __forceinline__ uint64_t bs_bit_range(int lo, int hi) {       // bits lo..hi of a 64-bit word, 0 <= lo <= hi <= 63
+    return (hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull);
 }
 
 __device__ __forceinline__ int bs_wave_max(int v) {
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(64) void gact_bs_kernel(const uint64_t *__restrict_
                                                      const uint64_t *__restrict__ cpl,
                                                      const uint32_t *__restrict__ tlens,
                                                      const uint32_t *__restrict__ rflags, uint64_t n_reads,
-                                                     int T, int O, uint32_t *__restrict__ ckpt,
+                                                     int T, int O, int W, uint32_t *__restrict__ ckpt,
                                                      uint64_t *__restrict__ codes, uint64_t cw,
                                                      int32_t *__restrict__ n_codes_out,
                                                      int32_t *__restrict__ n_ops_out,
@@ -310,6 +319,10 @@ __global__ __launch_bounds__(64) void gact_bs_kernel(const uint64_t *__restrict_
     const int cap = T - O, lim2 = 2 * cap;
     const int nblk = (lim2 + BS_K - 1) / BS_K;
     uint32_t *ckw = ckpt + (size_t) blockIdx.x * (size_t) nblk * 512;   // this wavefront's checkpoints (L2-resident scratch)
+    // band -W/2 <= b - a <= W/2 - 1 as bit ranges of the planes (even: d = 2t - 64, odd: d = 2t - 63)
+    const int hw = W / 2;
+    const uint64_t bandE64 = bs_bit_range((65 - hw) >> 1, (63 + hw) >> 1);
+    const uint64_t bandO64 = bs_bit_range((64 - hw) >> 1, (62 + hw) >> 1);
     int i = 0, j = 0, cnt = 0, score = 0;
     uint64_t sb = 0;               // code stream buffer: `fill` bits used
     int fill = 0, widx = 0;
@@ -371,6 +384,9 @@ __global__ __launch_bounds__(64) void gact_bs_kernel(const uint64_t *__restrict_
 
         BsState x = {{0u, 0u}, {~0u, ~0u}, {0u, 0u}, {~0u, ~0u}};
         BsStream st;
+        st.bandE.lo = (uint32_t) bandE64; st.bandE.hi = (uint32_t) (bandE64 >> 32);
+        st.bandO.lo = (uint32_t) bandO64; st.bandO.hi = (uint32_t) (bandO64 >> 32);
+        st.narrow = W < 128;
         BsPl nN, nG;
         // ---- pass 1: differences only, checkpoints at the block boundaries ----
         bs_stream_init(st, t, S0, 31);
@@ -545,7 +561,7 @@ uint64_t lrm_bs_planar_words(uint64_t len) { return 2 * ((len + 63) / 64) + 2 * 
 bool lrm_bs_wanted(lrm_gact_params gp, uint64_t n) {
     const char *e = getenv("LRM_GACT_IMPL");
     const int impl = e ? atoi(e) : 0;
-    return gp.W == 128 && (impl == 4 || (impl == 0 && n >= LRM_BS_MIN_READS));
+    return gp.W <= 128 && (impl == 4 || (impl == 0 && n >= LRM_BS_MIN_READS));
 }
 
 // planar text into a caller-provided buffer of lrm_bs_planar_words(len) words (+ a flag word)
@@ -612,7 +628,7 @@ uint64_t lrm_bs_ckpt_words(uint64_t n) {                     // T - O <= 512: at
 }
 
 int lrm_bs_launch(const LrmBsArgs *bs, const uint32_t *d_lens, const lrm_seq_meta *d_meta, const int32_t *d_meta_r,
-                  const uint32_t *d_tlens, uint64_t n, int T, int O, uint8_t *d_store, uint64_t store_stride,
+                  const uint32_t *d_tlens, uint64_t n, int T, int O, int W, uint8_t *d_store, uint64_t store_stride,
                   int32_t *d_n_ops, int32_t *d_score, LrmDevCounters *counters, void *stream_) {
     hipStream_t stream = (hipStream_t) stream_;
     uint64_t blocks = (n + 63) / 64;
@@ -623,7 +639,7 @@ int lrm_bs_launch(const LrmBsArgs *bs, const uint32_t *d_lens, const lrm_seq_met
     }
     HIPCHK(hipMemsetAsync(&counters->reserved[0], 0, sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(gact_bs_kernel, dim3((uint32_t) blocks), dim3(64), 0, stream, bs->qpl, bs->wpr, d_lens, d_meta,
-                       d_meta_r, bs->cpl + BS_PADW, d_tlens, bs->flags, n, T, O, bs->ckpt, bs->codes, bs->cw,
+                       d_meta_r, bs->cpl + BS_PADW, d_tlens, bs->flags, n, T, O, W, bs->ckpt, bs->codes, bs->cw,
                        bs->ncodes, d_n_ops, d_score, counters);
     const uint32_t bpr = (uint32_t) ((bs->cw * 32 + 4095) / 4096);          // 256 threads x 16 columns per block
     if (n * bpr > 0x7fffffffull) { lrm_set_error("expand grid too large: split the batch"); return -1; }

@@ -838,7 +838,7 @@ static int gact_launch(lrm_gact_params gp, uint64_t n, hipStream_t stream, const
         return 0;
     }
     // LRM_GACT_IMPL (read at every call so that tests can switch): 0 = automatic, 1 = one read per wavefront,
-    // 3 = packed two reads per wavefront, 4 = bit-sliced lane per read whenever it applies (W = 128, pure ACGT
+    // 3 = packed two reads per wavefront, 4 = bit-sliced lane per read whenever it applies (W <= 128, pure ACGT
     // text, 4-byte aligned CIGAR store; otherwise as 0)
     int impl = 0;
     { const char *e = getenv("LRM_GACT_IMPL"); impl = e ? atoi(e) : 0; }
@@ -847,14 +847,14 @@ static int gact_launch(lrm_gact_params gp, uint64_t n, hipStream_t stream, const
     const int nblk = ((2 * (gp.T - gp.O) - 1) >> 4) + 1;
     // Bit-sliced kernel: a wavefront carries 64 reads, so it needs a large batch to fill the chip
     // (below ~16 k reads the two-reads-per-wavefront kernel finishes first).
-    const bool bs_ok = bs && bs->cpl && gp.W == 128 && (((uintptr_t) store | (uintptr_t) store_stride) & 3u) == 0;
+    const bool bs_ok = bs && bs->cpl && gp.W <= 128 && (((uintptr_t) store | (uintptr_t) store_stride) & 3u) == 0;
     if (bs_ok && (impl == 4 || (impl == 0 && n >= LRM_BS_MIN_READS))) {
-        if (lrm_bs_launch(bs, lens, meta, meta_r, tlens, n, gp.T, gp.O, store, store_stride, n_ops, score, counters,
+        if (lrm_bs_launch(bs, lens, meta, meta_r, tlens, n, gp.T, gp.O, gp.W, store, store_stride, n_ops, score, counters,
                           stream)) return -1;
         // reads holding a byte other than ACGT (rare): byte kernel, flagged reads only
         GactLds L1 = gact_lds_layout(gp.T, gp.O);
         size_t sh1 = (size_t) L1.wave_bytes * 4;
-        gact1_fn_t f1 = gact_kernel<true>;
+        gact1_fn_t f1 = gp.W >= 128 ? gact_kernel<true> : gact_kernel<false>;
         if (sh1 > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(f1),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) sh1);

@@ -150,12 +150,12 @@ struct LrmBsArgs {
 uint64_t lrm_bs_planar_words(uint64_t len);
 uint64_t lrm_bs_code_words(uint32_t max_len);
 uint64_t lrm_bs_ckpt_words(uint64_t n);
-bool lrm_bs_wanted(lrm_gact_params gp, uint64_t n);      // W = 128 and (LRM_GACT_IMPL=4 or automatic with a large batch)
+bool lrm_bs_wanted(lrm_gact_params gp, uint64_t n);      // W <= 128 and (LRM_GACT_IMPL=4 or automatic with a large batch)
 int lrm_bs_pack_reads(const char *d_reads, uint64_t stride, const uint32_t *d_lens, uint64_t n, uint32_t max_len,
                       uint64_t *d_qpl, uint64_t wpr, uint32_t *d_flags, void *stream);
 int lrm_bs_pack_text(const char *d_text, uint64_t len, uint64_t *d_out, uint32_t *d_flag, void *stream);
 int lrm_bs_launch(const LrmBsArgs *bs, const uint32_t *d_lens, const lrm_seq_meta *d_meta, const int32_t *d_meta_r,
-                  const uint32_t *d_tlens, uint64_t n, int T, int O, uint8_t *d_store, uint64_t store_stride,
+                  const uint32_t *d_tlens, uint64_t n, int T, int O, int W, uint8_t *d_store, uint64_t store_stride,
                   int32_t *d_n_ops, int32_t *d_score, LrmDevCounters *counters, void *stream);
 int lrm_bs_prepare_index(lrm_index *idx);
 int lrm_lcl_prepare_index(lrm_index *idx);       // seed_kernels.hip: the long seed table

@@ -10,7 +10,7 @@
  *   cell (a,b), u = H(a+1,b), w = V(a,b+1), s = +1/-1:
  *       X = R[a][b] - R[a+1][b+1] = max(s, u-1, w-1);  V(a,b) = X - u;  H(a,b) = X - w
  *       DIAG iff s >= u-1 and s >= w-1;  else INS iff u >= w;  else DEL
- *   band W = 128: anti-diagonal s holds 64 cells t = 0..63, diagonal d = 2t - 64 (+1 when s is odd),
+ *   band W <= 128: anti-diagonal s holds 64 cells t = 0..63, diagonal d = 2t - 64 (+1 when s is odd),
  *       a = A0 - t, b = B0 + t with A0 = (s + 64 - (s&1)) >> 1, B0 = s - A0.
  *   neighbours: even s: u = H_prev << 1, w = V_prev;  odd s: u = H_prev, w = V_prev >> 1 (zeros shifted
  *       in = code 0 = "never wins" = the out-of-band -inf).
@@ -141,6 +141,13 @@ static void d_transition(bs_stream *st, const bs_tile *t) {            /* after 
 typedef struct { uint64_t V1, V0, H1, H0; } bs_state;
 
 /* one anti-diagonal; N/G: traceback planes (N = not diagonal; G = deletion if N else mismatch) */
+static uint64_t bit_range(int lo, int hi) {
+    return (hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull);
+}
+/* lattice points inside the band -W/2 <= b - a <= W/2 - 1 on even (d = 2t - 64) / odd (d = 2t - 63) anti-diagonals;
+ * points outside a band narrower than the planes hold code 0 (-1): as a neighbour it never wins */
+static uint64_t g_bandE = ~0ull, g_bandO = ~0ull;
+
 static void bs_step(bs_state *x, const bs_stream *st, int odd, uint64_t *Nout, uint64_t *Gout) {
     uint64_t u1, u0, w1, w0;
     if (!odd) { u1 = x->H1 << 1; u0 = x->H0 << 1; w1 = x->V1; w0 = x->V0; }
@@ -152,14 +159,21 @@ static void bs_step(bs_state *x, const bs_stream *st, int odd, uint64_t *Nout, u
     uint64_t V1 = (m & ~u1) | (del & n1), V0 = (~nd & ~u0) | (del & d0);
     uint64_t H1 = (m & ~w1) | (ins & d1), H0 = (~nd & ~w0) | (ins & d0);
     const uint64_t Bm = st->Q[2] | st->D[2];
-    x->V1 = V1 & ~Bm; x->V0 = V0 | Bm; x->H1 = H1 & ~Bm; x->H0 = H0 | Bm;
+    const uint64_t band = odd ? g_bandO : g_bandE;
+    x->V1 = V1 & ~Bm & band; x->V0 = (V0 | Bm) & band; x->H1 = H1 & ~Bm & band; x->H0 = (H0 | Bm) & band;
     if (Nout) { *Nout = nd; *Gout = del | ~(m | big); }
 }
 
 /* returns the score (X + I + D) or -1 (non-ACGT input: the kernel routes such reads to the byte kernels) */
-int bsm_gact(const char *q, int n, const char *d, int m, int T, int O, int extra_s0,
+int bsm_gact(const char *q, int n, const char *d, int m, int T, int O, int W, int extra_s0,
              uint8_t *ops, int *n_ops) {
     *n_ops = 0;
+    if (W < 2 || W > 128 || (W & 1)) return -1;
+    {
+        const int hw = W / 2;
+        g_bandE = bit_range((65 - hw) >> 1, (63 + hw) >> 1);
+        g_bandO = bit_range((64 - hw) >> 1, (62 + hw) >> 1);
+    }
     bs_word *qb, *db;
     bs_word *qpl = bs_pack(q, n, &qb);
     if (!qpl) return -1;

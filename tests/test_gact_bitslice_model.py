@@ -24,13 +24,13 @@ def model():
         subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", LIB, SRC])
     lib = C.CDLL(LIB)
     lib.bsm_gact.restype = C.c_int
-    lib.bsm_gact.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+    lib.bsm_gact.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                              C.POINTER(C.c_int)]
 
-    def run(q, d, T, O, extra=0):
+    def run(q, d, T, O, extra=0, W=128):
         ops = np.zeros(len(q) + len(d) + 8, dtype=np.uint8)
         n_ops = C.c_int()
-        score = lib.bsm_gact(q, len(q), d, len(d), T, O, extra, ops.ctypes.data, C.byref(n_ops))
+        score = lib.bsm_gact(q, len(q), d, len(d), T, O, W, extra, ops.ctypes.data, C.byref(n_ops))
         return score, bytes(ops[:n_ops.value])
     return run
 
@@ -50,17 +50,18 @@ def _noisy(rng, d, n, err):
     return bytes(q)
 
 
+@pytest.mark.parametrize("W", [128, 64, 32, 66, 20, 2])
 @pytest.mark.parametrize("T,O", [(320, 120), (512, 120), (512, 0), (100, 99), (64, 16), (33, 7), (16, 0), (200, 40)])
-def test_model_equals_oracle(model, T, O):
-    rng = np.random.default_rng(T * 7 + O)
-    for it in range(60):
+def test_model_equals_oracle(model, T, O, W):
+    rng = np.random.default_rng(T * 7 + O + W)
+    for it in range(60 if W == 128 else 25):
         m = int(rng.integers(1, 2500 if it % 6 == 0 else 700))
         d = bytes(rng.choice(list(b"ACGT"), size=m).astype(np.uint8))
         n = m if it % 3 == 0 else int(rng.integers(1, 900))
         q = _noisy(rng, d, n, float(rng.integers(0, 30)) / 100)
         extra = int(rng.integers(0, 3)) * 16              # a wave-wide start above this lane's own tile corner
-        want = orc.gact(q, d, T, O, 128)
-        assert model(q, d, T, O, extra) == (want[0], want[1]), (it, n, m)
+        want = orc.gact(q, d, T, O, W)
+        assert model(q, d, T, O, extra, W) == (want[0], want[1]), (it, n, m)
 
 
 def test_model_rejects_other_bytes(model):

@@ -67,16 +67,17 @@ def test_ultralong_100k_gact_sweep(ref3, T, O, W):
     _compare(di, oi, r["reads"], r["lens"], (T, O, W))
 
 
-@pytest.mark.parametrize("T,O", [(256, 64), (320, 32), (320, 120), (512, 120)])
-def test_ultralong_100k_bitsliced(ref3, monkeypatch, T, O):
-    """The W = 128 points of the config-4 sweep through the lane-per-read kernel (500 tiles per read), reads of
+@pytest.mark.parametrize("T,O,W", [(256, 64, 128), (320, 32, 128), (320, 120, 128), (512, 120, 128),
+                                   (128, 32, 32), (128, 64, 64), (256, 120, 64), (320, 120, 32), (512, 64, 64)])
+def test_ultralong_100k_bitsliced(ref3, monkeypatch, T, O, W):
+    """The W <= 128 points of the config-4 sweep through the lane-per-read kernel (500 tiles per read), reads of
     100 kbp next to short ones so that lanes finish at very different times."""
     monkeypatch.setenv("LRM_GACT_IMPL", "4")
     seqs, hi, di, oi = ref3
     r = synth.reads(seqs, 6, 100_000, synth.ONT, seed=17)
     lens = r["lens"].copy()
     lens[1], lens[4] = 7_000, 333
-    _compare(di, oi, r["reads"], lens, (T, O, 128))
+    _compare(di, oi, r["reads"], lens, (T, O, W))
 
 
 def test_pacbio_and_multiseq_bitsliced(ref3, monkeypatch):

@@ -77,7 +77,9 @@ def test_gact_kernel_vs_oracle(gpu, T, O, W):
 
 
 BS_PARAMS = [(320, 120, 128), (512, 120, 128), (100, 99, 128), (320, 0, 128), (64, 16, 128), (33, 7, 128), (16, 0, 128),
-             (512, 0, 128)]
+             (512, 0, 128),
+             (320, 120, 64), (320, 120, 32), (128, 32, 64), (64, 16, 32), (16, 0, 2), (320, 120, 20), (33, 7, 66),
+             (256, 120, 64), (512, 64, 64)]          # bands narrower than the 128 diagonals of the planes
 
 
 @pytest.mark.parametrize("T,O,W", BS_PARAMS)
@@ -87,6 +89,8 @@ def test_gact_bitsliced_kernel_vs_oracle(gpu, monkeypatch, T, O, W):
     rng = np.random.default_rng(T * 1000 + O * 10 + 7)
     ref = bytes(synth.reference(20000, seed=3))
     sizes = [1, 2, 5, 31, 63, 64, 65, 127, 199, 200, 201, 319, 320, 321, 500, 1000, 2500]
+    if W != 128:
+        sizes = sizes[::2]
     for n in sizes:
         for prof in ((0, 0, 0), (0.04, 0.03, 0.03), (0.015, 0.09, 0.045), (0.2, 0.1, 0.1)):
             p = int(rng.integers(0, len(ref) - 3 * n - 64))
