@@ -20,7 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define BS_K 16                 /* anti-diagonals per traceback block (the kernel's value) */
+#define BS_K 32                 /* anti-diagonals per traceback block (the kernel's value) */
 #define BS_PAD 8                /* planar words of padding on either side of a sequence */
 
 typedef struct { uint32_t lo, hi; } bs_word;      /* 32 bases: bit k of lo/hi = low/high code bit of base k */

@@ -59,7 +59,7 @@ def test_model_equals_oracle(model, T, O, W):
         d = bytes(rng.choice(list(b"ACGT"), size=m).astype(np.uint8))
         n = m if it % 3 == 0 else int(rng.integers(1, 900))
         q = _noisy(rng, d, n, float(rng.integers(0, 30)) / 100)
-        extra = int(rng.integers(0, 3)) * 16              # a wave-wide start above this lane's own tile corner
+        extra = int(rng.integers(0, 3)) * 32              # a wave-wide start above this lane's own tile corner
         want = orc.gact(q, d, T, O, W)
         assert model(q, d, T, O, extra, W) == (want[0], want[1]), (it, n, m)
 
