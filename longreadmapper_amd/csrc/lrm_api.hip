@@ -254,31 +254,53 @@ struct DevSlot {
     void release() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
 };
 #define LRM_STAGE_CHUNK (32ull << 20)
+struct DevSet { DevSlot reads, lens, best, store, nops, score, meta, mr; };
 struct HostCache {
     lrm_workspace *ws;
-    DevSlot reads, lens, best, store, nops, score, meta, mr;
-    void *pin[2]; hipStream_t copy; hipEvent_t ev[2]; int staging_ready;
+    DevSet set[2];                       // a batch goes through the device in sub-batches, alternating between the sets
+    void *pin_up[2], *pin_dn[2];         // pinned staging chunks per direction
+    hipStream_t up, down, comp;          // upload DMA, download DMA, kernels
+    hipEvent_t ev_pin_up[2], ev_pin_dn[2], ev_up[2], ev_done[2];
+    int pin_up_used[2];
+    uint64_t up_seq;
+    int staging_ready;
 };
 static thread_local HostCache g_cache = {};
 
 static int staging_init(HostCache &c) {
     if (c.staging_ready) return 0;
     for (int b = 0; b < 2; ++b) {
-        if (hipHostMalloc(&c.pin[b], LRM_STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) { lrm_set_error("pinned staging allocation failed"); return -1; }
-        if (hipEventCreateWithFlags(&c.ev[b], hipEventDisableTiming) != hipSuccess) { lrm_set_error("event creation failed"); return -1; }
+        if (hipHostMalloc(&c.pin_up[b], LRM_STAGE_CHUNK, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&c.pin_dn[b], LRM_STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) { lrm_set_error("pinned staging allocation failed"); return -1; }
+        if (hipEventCreateWithFlags(&c.ev_pin_up[b], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c.ev_pin_dn[b], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c.ev_up[b], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c.ev_done[b], hipEventDisableTiming) != hipSuccess) { lrm_set_error("event creation failed"); return -1; }
+        c.pin_up_used[b] = 0;
     }
-    if (hipStreamCreateWithFlags(&c.copy, hipStreamNonBlocking) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
+    if (hipStreamCreateWithFlags(&c.up, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c.down, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c.comp, hipStreamNonBlocking) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
+    c.up_seq = 0;
     c.staging_ready = 1;
     return 0;
 }
 static void staging_release(HostCache &c) {
     if (c.staging_ready) {
-        for (int b = 0; b < 2; ++b) { (void) hipHostFree(c.pin[b]); (void) hipEventDestroy(c.ev[b]); }
-        (void) hipStreamDestroy(c.copy);
+        (void) hipDeviceSynchronize();
+        for (int b = 0; b < 2; ++b) {
+            (void) hipHostFree(c.pin_up[b]); (void) hipHostFree(c.pin_dn[b]);
+            (void) hipEventDestroy(c.ev_pin_up[b]); (void) hipEventDestroy(c.ev_pin_dn[b]);
+            (void) hipEventDestroy(c.ev_up[b]); (void) hipEventDestroy(c.ev_done[b]);
+        }
+        (void) hipStreamDestroy(c.up); (void) hipStreamDestroy(c.down); (void) hipStreamDestroy(c.comp);
         c.staging_ready = 0;
     }
-    c.reads.release(); c.lens.release(); c.best.release(); c.store.release();
-    c.nops.release(); c.score.release(); c.meta.release(); c.mr.release();
+    for (int b = 0; b < 2; ++b) {
+        DevSet &d = c.set[b];
+        d.reads.release(); d.lens.release(); d.best.release(); d.store.release();
+        d.nops.release(); d.score.release(); d.meta.release(); d.mr.release();
+    }
 }
 #define LRM_COPY_THREADS 8        // enough to outrun the link; a library must not fan out over every core of its host
 static void par_memcpy(void *dst, const void *src, uint64_t bytes) {
@@ -289,19 +311,24 @@ static void par_memcpy(void *dst, const void *src, uint64_t bytes) {
         memcpy((char *) dst + o, (const char *) src + o, l);
     }
 }
-// host -> device through the pinned chunks
+// host -> device through the pinned chunks, enqueued on the upload stream; returns when the last chunk has been
+// handed to the DMA engine (not when it has landed: order later work behind the upload stream)
 static int stage_h2d(HostCache &c, void *d_dst, const void *h_src, uint64_t bytes) {
     if (staging_init(c)) return -1;
-    uint64_t k = 0;
-    for (uint64_t o = 0; o < bytes; o += LRM_STAGE_CHUNK, ++k) {
-        const int b = (int) (k & 1);
+    for (uint64_t o = 0; o < bytes; o += LRM_STAGE_CHUNK, ++c.up_seq) {
+        const int b = (int) (c.up_seq & 1);
         const uint64_t l = bytes - o < LRM_STAGE_CHUNK ? bytes - o : LRM_STAGE_CHUNK;
-        if (k >= 2) HIPCHK(hipEventSynchronize(c.ev[b]));             // the chunk's previous DMA has drained
-        par_memcpy(c.pin[b], (const char *) h_src + o, l);
-        HIPCHK(hipMemcpyAsync((char *) d_dst + o, c.pin[b], l, hipMemcpyHostToDevice, c.copy));
-        HIPCHK(hipEventRecord(c.ev[b], c.copy));
+        if (c.pin_up_used[b]) HIPCHK(hipEventSynchronize(c.ev_pin_up[b]));     // the chunk's previous DMA has drained
+        par_memcpy(c.pin_up[b], (const char *) h_src + o, l);
+        HIPCHK(hipMemcpyAsync((char *) d_dst + o, c.pin_up[b], l, hipMemcpyHostToDevice, c.up));
+        HIPCHK(hipEventRecord(c.ev_pin_up[b], c.up));
+        c.pin_up_used[b] = 1;
     }
-    HIPCHK(hipStreamSynchronize(c.copy));
+    return 0;
+}
+// small host array -> device behind the staged upload (pageable source: the call returns once it is staged)
+static int small_h2d(HostCache &c, void *d_dst, const void *h_src, uint64_t bytes) {
+    HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c.up));
     return 0;
 }
 // device -> host, `rows` rows of `width` bytes (device pitch spitch, host pitch dpitch); rows == 1 is a flat copy
@@ -318,19 +345,19 @@ static int stage_d2h(HostCache &c, void *h_dst, uint64_t dpitch, const void *d_s
         const int b = (int) (k & 1);
         const uint64_t l = o < total ? (total - o < unit ? total - o : unit) : 0;
         if (l) {
-            if (flat) HIPCHK(hipMemcpyAsync(c.pin[b], (const char *) d_src + o, l, hipMemcpyDeviceToHost, c.copy));
-            else HIPCHK(hipMemcpy2DAsync(c.pin[b], width, (const char *) d_src + o * spitch, spitch, width, l,
-                                         hipMemcpyDeviceToHost, c.copy));
-            HIPCHK(hipEventRecord(c.ev[b], c.copy));
+            if (flat) HIPCHK(hipMemcpyAsync(c.pin_dn[b], (const char *) d_src + o, l, hipMemcpyDeviceToHost, c.down));
+            else HIPCHK(hipMemcpy2DAsync(c.pin_dn[b], width, (const char *) d_src + o * spitch, spitch, width, l,
+                                         hipMemcpyDeviceToHost, c.down));
+            HIPCHK(hipEventRecord(c.ev_pin_dn[b], c.down));
         }
         if (prev_l) {                                                 // unpack the previous chunk while this one flies
             const int pb = (int) ((k - 1) & 1);
-            HIPCHK(hipEventSynchronize(c.ev[pb]));
-            if (flat) par_memcpy((char *) h_dst + prev_o, c.pin[pb], prev_l);
+            HIPCHK(hipEventSynchronize(c.ev_pin_dn[pb]));
+            if (flat) par_memcpy((char *) h_dst + prev_o, c.pin_dn[pb], prev_l);
             else {
 #pragma omp parallel for schedule(static) num_threads(LRM_COPY_THREADS)
                 for (uint64_t r = 0; r < prev_l; ++r)
-                    memcpy((char *) h_dst + (prev_o + r) * dpitch, (const char *) c.pin[pb] + r * width, width);
+                    memcpy((char *) h_dst + (prev_o + r) * dpitch, (const char *) c.pin_dn[pb] + r * width, width);
             }
         }
         if (l == 0) break;
@@ -557,21 +584,49 @@ static uint64_t host_slice_reads(uint32_t max_len) {
     return r < 16384 ? 16384 : r;
 }
 
+// Sub-batches of one device pass: the upload of sub-batch k+1 (host memcpy into pinned chunks + DMA) and the
+// download of sub-batch k-1 run while the kernels of sub-batch k execute on their own stream.
+#define LRM_PIPE_MIN_READS 16384
+static uint64_t pipe_subs(uint64_t n) {
+    if (const char *e = getenv("LRM_HOST_SUBS")) { const long long v = atoll(e); if (v >= 1) return (uint64_t) v < n ? (uint64_t) v : n; }   // test knob
+    const uint64_t k = n / LRM_PIPE_MIN_READS;
+    return k < 2 ? 1 : (k > 4 ? 4 : k);
+}
+
 static int seed_slice(lrm_index *idx, const char *reads_buf, uint64_t stride, const uint32_t *lens, uint64_t n,
                       uint32_t max_len, lrm_params p, lrm_entry *best_out) {
-    lrm_workspace *ws;
-    if (get_cached_ws(idx, n, max_len, p.seed_len, p.thres, &ws)) return -1;
     HostCache &hc = g_cache;
-    DevSlot &d_reads = hc.reads, &d_lens = hc.lens, &d_best = hc.best;
-    if (d_reads.ensure(n * stride) || d_lens.ensure(n * 4) || d_best.ensure(n * sizeof(lrm_entry))) { lrm_set_error("device allocation failed"); return -1; }
-    if (stage_h2d(hc, d_reads.p, reads_buf, n * stride)) return -1;
-    HIPCHK(hipMemcpy(d_lens.p, lens, n * 4, hipMemcpyHostToDevice));
-    if (lrm_launch_seed(idx, ws, (const char *) d_reads.p, stride, (const uint32_t *) d_lens.p, n, max_len, p.seed_len,
-                        p.thres, (lrm_entry *) d_best.p, nullptr)) return -1;
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(best_out, d_best.p, n * sizeof(lrm_entry), hipMemcpyDeviceToHost));
+    if (staging_init(hc)) return -1;
+    const uint64_t nsub = pipe_subs(n), sub = (n + nsub - 1) / nsub;
+    lrm_workspace *ws;
+    if (get_cached_ws(idx, sub, max_len, p.seed_len, p.thres, &ws)) return -1;
+    uint64_t prev_off = 0, prev_m = 0;
+    for (uint64_t k = 0, off = 0; off < n; ++k, off += sub) {
+        const int b = (int) (k & 1);
+        const uint64_t m = n - off < sub ? n - off : sub;
+        DevSet &d = hc.set[b];
+        if (d.reads.ensure(m * stride) || d.lens.ensure(m * 4) || d.best.ensure(m * sizeof(lrm_entry))) { lrm_set_error("device allocation failed"); return -1; }
+        if (stage_h2d(hc, d.reads.p, reads_buf + off * stride, m * stride)) return -1;
+        if (small_h2d(hc, d.lens.p, lens + off, m * 4)) return -1;
+        HIPCHK(hipEventRecord(hc.ev_up[b], hc.up));
+        HIPCHK(hipStreamWaitEvent(hc.comp, hc.ev_up[b], 0));
+        if (lrm_launch_seed(idx, ws, (const char *) d.reads.p, stride, (const uint32_t *) d.lens.p, m, max_len, p.seed_len,
+                            p.thres, (lrm_entry *) d.best.p, hc.comp)) return -1;
+        HIPCHK(hipEventRecord(hc.ev_done[b], hc.comp));
+        if (prev_m) {                                              // results of the previous sub-batch
+            const int pb = (int) ((k - 1) & 1);
+            HIPCHK(hipEventSynchronize(hc.ev_done[pb]));
+            HIPCHK(hipMemcpy(best_out + prev_off, hc.set[pb].best.p, prev_m * sizeof(lrm_entry), hipMemcpyDeviceToHost));
+        }
+        prev_off = off; prev_m = m;
+    }
+    {
+        const int pb = (int) (((n + sub - 1) / sub - 1) & 1);
+        HIPCHK(hipEventSynchronize(hc.ev_done[pb]));
+        HIPCHK(hipMemcpy(best_out + prev_off, hc.set[pb].best.p, prev_m * sizeof(lrm_entry), hipMemcpyDeviceToHost));
+    }
     lrm_stats st;
-    if (lrm_workspace_stats(ws, &st, nullptr)) return -1;
+    if (lrm_workspace_stats(ws, &st, hc.comp)) return -1;
     return 0;
 }
 
@@ -590,47 +645,71 @@ extern "C" int lrm_seed_batch(lrm_index *idx, const char *reads_buf, uint64_t st
     return 0;
 }
 
-static int extend_slice(lrm_index *idx, char *reads_buf, uint64_t stride, const uint32_t *lens, uint64_t n,
-                        uint32_t max_len, const lrm_entry *best, lrm_gact_params gp, lrm_cigar *cig_out,
-                        uint8_t *store_mem, uint64_t store_stride, int *score_out, lrm_seq_meta *meta_out,
-                        int *meta_r_out) {
-    lrm_workspace *ws = g_cache.ws;
-    if (!ws || ws->idx != idx) {
-        if (get_cached_ws(idx, n, max_len, 20, 300, &ws)) return -1;   // extend only needs the counters block
-    }
-    const uint64_t dstride = (store_stride + 3) & ~3ull;     // the bit-sliced kernel stores CIGAR bytes four at a time
-    HostCache &hc = g_cache;
-    DevSlot &d_reads = hc.reads, &d_lens = hc.lens, &d_best = hc.best, &d_store = hc.store, &d_nops = hc.nops,
-            &d_score = hc.score, &d_meta = hc.meta, &d_mr = hc.mr;
-    if (d_reads.ensure(n * stride) || d_lens.ensure(n * 4) || d_best.ensure(n * sizeof(lrm_entry)) ||
-        d_store.ensure(n * dstride) || d_nops.ensure(n * 4) || d_score.ensure(n * 4) ||
-        d_meta.ensure(n * sizeof(lrm_seq_meta)) || d_mr.ensure(n * 4)) { lrm_set_error("device allocation failed"); return -1; }
-    if (stage_h2d(hc, d_reads.p, reads_buf, n * stride)) return -1;
-    HIPCHK(hipMemcpy(d_lens.p, lens, n * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_best.p, best, n * sizeof(lrm_entry), hipMemcpyHostToDevice));
-    if (lrm_launch_extend(idx, ws, (char *) d_reads.p, stride, (const uint32_t *) d_lens.p, n, max_len,
-                          (const lrm_entry *) d_best.p, gp, (uint8_t *) d_store.p, dstride, (int32_t *) d_nops.p,
-                          (int32_t *) d_score.p, (lrm_seq_meta *) d_meta.p, (int32_t *) d_mr.p, nullptr)) return -1;
-    HIPCHK(hipDeviceSynchronize());
-    std::vector<int32_t> nops(n);
-    HIPCHK(hipMemcpy(nops.data(), d_nops.p, n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(score_out, d_score.p, n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(meta_out, d_meta.p, n * sizeof(lrm_seq_meta), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(meta_r_out, d_mr.p, n * 4, hipMemcpyDeviceToHost));
-    if (stage_d2h(hc, reads_buf, 0, d_reads.p, 0, n * stride, 1)) return -1;          // rev-comped reads travel back
-    {
-        int32_t mx = 0;                                              // only the columns some read uses cross the link
-        for (uint64_t i = 0; i < n; ++i) mx = nops[i] > mx ? nops[i] : mx;
-        uint64_t width = ((uint64_t) mx + 63) & ~63ull;
-        if (width > store_stride) width = store_stride;
-        if (stage_d2h(hc, store_mem, store_stride, d_store.p, dstride, width, n)) return -1;
-    }
-    for (uint64_t i = 0; i < n; ++i) {                                              // alnmain.c:322-325, mutils.c:99-104
+static int extend_collect(HostCache &hc, int b, uint64_t m, char *reads_buf, uint64_t stride, lrm_cigar *cig_out,
+                          uint8_t *store_mem, uint64_t store_stride, uint64_t dstride, int *score_out,
+                          lrm_seq_meta *meta_out, int *meta_r_out) {
+    DevSet &d = hc.set[b];
+    HIPCHK(hipEventSynchronize(hc.ev_done[b]));
+    std::vector<int32_t> nops(m);
+    HIPCHK(hipMemcpy(nops.data(), d.nops.p, m * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(score_out, d.score.p, m * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(meta_out, d.meta.p, m * sizeof(lrm_seq_meta), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(meta_r_out, d.mr.p, m * 4, hipMemcpyDeviceToHost));
+    if (stage_d2h(hc, reads_buf, 0, d.reads.p, 0, m * stride, 1)) return -1;          // rev-comped reads travel back
+    int32_t mx = 0;                                                  // only the columns some read uses cross the link
+    for (uint64_t i = 0; i < m; ++i) mx = nops[i] > mx ? nops[i] : mx;
+    uint64_t width = ((uint64_t) mx + 63) & ~63ull;
+    if (width > store_stride) width = store_stride;
+    if (stage_d2h(hc, store_mem, store_stride, d.store.p, dstride, width, m)) return -1;
+    for (uint64_t i = 0; i < m; ++i) {                               // alnmain.c:322-325, mutils.c:99-104
         cig_out[i].cigar = store_mem + i * store_stride;
         cig_out[i].n_cigar_op = nops[i];
         cig_out[i].score = score_out[i];
     }
     return 0;
+}
+
+static int extend_slice(lrm_index *idx, char *reads_buf, uint64_t stride, const uint32_t *lens, uint64_t n,
+                        uint32_t max_len, const lrm_entry *best, lrm_gact_params gp, lrm_cigar *cig_out,
+                        uint8_t *store_mem, uint64_t store_stride, int *score_out, lrm_seq_meta *meta_out,
+                        int *meta_r_out) {
+    HostCache &hc = g_cache;
+    if (staging_init(hc)) return -1;
+    const uint64_t nsub = pipe_subs(n), sub = (n + nsub - 1) / nsub;
+    lrm_workspace *ws = hc.ws;
+    if (!ws || ws->idx != idx) {
+        if (get_cached_ws(idx, sub, max_len, 20, 300, &ws)) return -1;   // extend only needs the counters block and the GACT scratch
+    } else if (sub > ws->n_max || max_len > ws->max_len) {
+        const uint32_t sl = ws->seed_len, th = ws->thres;
+        if (get_cached_ws(idx, sub, max_len, sl, th, &ws)) return -1;
+    }
+    const uint64_t dstride = (store_stride + 3) & ~3ull;     // the bit-sliced kernel stores CIGAR bytes four at a time
+    uint64_t prev_off = 0, prev_m = 0;
+    uint64_t k = 0;
+    for (uint64_t off = 0; off < n; ++k, off += sub) {
+        const int b = (int) (k & 1);
+        const uint64_t m = n - off < sub ? n - off : sub;
+        DevSet &d = hc.set[b];
+        if (d.reads.ensure(m * stride) || d.lens.ensure(m * 4) || d.best.ensure(m * sizeof(lrm_entry)) ||
+            d.store.ensure(m * dstride) || d.nops.ensure(m * 4) || d.score.ensure(m * 4) ||
+            d.meta.ensure(m * sizeof(lrm_seq_meta)) || d.mr.ensure(m * 4)) { lrm_set_error("device allocation failed"); return -1; }
+        if (stage_h2d(hc, d.reads.p, reads_buf + off * stride, m * stride)) return -1;
+        if (small_h2d(hc, d.lens.p, lens + off, m * 4)) return -1;
+        if (small_h2d(hc, d.best.p, best + off, m * sizeof(lrm_entry))) return -1;
+        HIPCHK(hipEventRecord(hc.ev_up[b], hc.up));
+        HIPCHK(hipStreamWaitEvent(hc.comp, hc.ev_up[b], 0));
+        if (lrm_launch_extend(idx, ws, (char *) d.reads.p, stride, (const uint32_t *) d.lens.p, m, max_len,
+                              (const lrm_entry *) d.best.p, gp, (uint8_t *) d.store.p, dstride, (int32_t *) d.nops.p,
+                              (int32_t *) d.score.p, (lrm_seq_meta *) d.meta.p, (int32_t *) d.mr.p, hc.comp)) return -1;
+        HIPCHK(hipEventRecord(hc.ev_done[b], hc.comp));
+        if (prev_m && extend_collect(hc, (int) ((k - 1) & 1), prev_m, reads_buf + prev_off * stride, stride,
+                                     cig_out + prev_off, store_mem + prev_off * store_stride, store_stride, dstride,
+                                     score_out + prev_off, meta_out + prev_off, meta_r_out + prev_off)) return -1;
+        prev_off = off; prev_m = m;
+    }
+    return extend_collect(hc, (int) ((k - 1) & 1), prev_m, reads_buf + prev_off * stride, stride, cig_out + prev_off,
+                          store_mem + prev_off * store_stride, store_stride, dstride, score_out + prev_off,
+                          meta_out + prev_off, meta_r_out + prev_off);
 }
 
 extern "C" int lrm_extend_batch(lrm_index *idx, char *reads_buf, uint64_t stride, const uint32_t *lens, uint64_t n,

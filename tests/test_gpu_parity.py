@@ -335,17 +335,22 @@ def test_host_batches_are_sliced_without_changing_results(dev_indexes, monkeypat
     best = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
     r1 = sc["reads"].copy()
     e1 = mapper.extend_batch(di, r1, sc["lens"], best)
-    monkeypatch.setenv("LRM_HOST_SLICE", "7")
-    best2 = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
-    r2 = sc["reads"].copy()
-    e2 = mapper.extend_batch(di, r2, sc["lens"], best2)
-    assert np.array_equal(best, best2) and np.array_equal(r1, r2)
-    assert np.array_equal(e1["score"], e2["score"]) and np.array_equal(e1["n_ops"], e2["n_ops"])
-    for i in range(len(best)):
-        k = int(e1["n_ops"][i])
-        assert bytes(e1["ops"][i, :k]) == bytes(e2["ops"][i, :k]), i
-    for f in ("loc", "off", "seq_id", "strand"):
-        assert np.array_equal(e1["meta"][f], e2["meta"][f])
+    # slices of 7 reads; then one slice cut into 5 pipelined sub-batches (upload k+1 / kernels k / download k-1)
+    for env in ({"LRM_HOST_SLICE": "7"}, {"LRM_HOST_SUBS": "5"}, {"LRM_HOST_SLICE": "23", "LRM_HOST_SUBS": "2"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        best2 = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+        r2 = sc["reads"].copy()
+        e2 = mapper.extend_batch(di, r2, sc["lens"], best2)
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        assert np.array_equal(best, best2) and np.array_equal(r1, r2), env
+        assert np.array_equal(e1["score"], e2["score"]) and np.array_equal(e1["n_ops"], e2["n_ops"]), env
+        for i in range(len(best)):
+            k = int(e1["n_ops"][i])
+            assert bytes(e1["ops"][i, :k]) == bytes(e2["ops"][i, :k]), (env, i)
+        for f in ("loc", "off", "seq_id", "strand"):
+            assert np.array_equal(e1["meta"][f], e2["meta"][f]), env
 
 
 def test_blob_roundtrip_and_adopt(dev_indexes, gpu):
