@@ -67,8 +67,8 @@ def load_pmc_summary(args, n, Lr):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ref-len", type=int, default=ECOLI_N)
     ap.add_argument("--reads", type=int, default=100_000)
     ap.add_argument("--read-len", type=int, default=10_000)
