@@ -24,7 +24,8 @@
 __device__ __forceinline__ uint32_t base_code(uint32_t c) { return ((c >> 1) ^ (c >> 2)) & 3u; }
 
 // ----------------------------------------------------------------------------------------
-// pack2bit: one thread per output byte (4 bases).  Bases past the read end pack as 0.
+// pack2bit: one thread per output dword (16 bases: one 16-byte load -- rows start at any byte, the hardware
+// takes the unaligned dwords -- and one 4-byte store).  Bases past the read end pack as 0.
 // ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack2bit_kernel(const char *__restrict__ reads, uint64_t stride,
                                                        const uint32_t *__restrict__ lens,
@@ -33,18 +34,24 @@ __global__ __launch_bounds__(256) void pack2bit_kernel(const char *__restrict__ 
     uint64_t read = blockIdx.x / chunks_per_read;
     uint32_t chunk = blockIdx.x % chunks_per_read;
     if (read >= n) return;
-    uint64_t ob = (uint64_t) chunk * 256 + threadIdx.x;
-    if (ob >= bytes_per_read) return;
+    uint64_t ow = (uint64_t) chunk * 256 + threadIdx.x;
+    if (ow * 4 >= bytes_per_read) return;
     uint32_t len = lens[read];
     const uint8_t *r = (const uint8_t *) reads + read * stride;
-    uint64_t p = ob * 4;
+    uint64_t p = ow * 16;
     uint32_t v = 0;
+    if (p + 16 <= len) {
+        uint32_t w[4];
+        __builtin_memcpy(w, r + p, 16);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        uint32_t code = (p + t < len) ? base_code(r[p + t]) : 0u;
-        v |= code << (2 * t);
+        for (int t = 0; t < 16; ++t) v |= base_code((w[t >> 2] >> (8 * (t & 3))) & 0xffu) << (2 * t);
+    } else {
+        for (int t = 0; t < 16; ++t) {
+            uint32_t code = (p + t < len) ? base_code(r[p + t]) : 0u;
+            v |= code << (2 * t);
+        }
     }
-    out[read * bytes_per_read + ob] = (uint8_t) v;
+    *reinterpret_cast<uint32_t *>(out + read * bytes_per_read + ow * 4) = v;
 }
 
 // ----------------------------------------------------------------------------------------
@@ -770,7 +777,7 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
     ws->n_last = n;
     {
         uint64_t bpr = wpr * 8;
-        uint32_t cpr = (uint32_t) ((bpr + 255) / 256);
+        uint32_t cpr = (uint32_t) ((bpr / 4 + 255) / 256);
         uint64_t blocks = n * cpr;
         if (blocks > 0x7fffffffull) { lrm_set_error("pack2bit grid too large"); return -1; }
         lrm_time_begin(ws, LRM_K_PACK2BIT, stream);
@@ -845,7 +852,7 @@ int lrm_launch_debug_seed(lrm_index *idx, const char *d_read, uint32_t len, uint
     if (cap_q == 0) cap_q = 1;
     if ((uint64_t) cap_q * P > cap) { lrm_set_error("debug seed buffer too small"); return -1; }
     uint64_t bpr = words * 8;
-    uint32_t cpr = (uint32_t) ((bpr + 255) / 256);
+    uint32_t cpr = (uint32_t) ((bpr / 4 + 255) / 256);
     uint32_t *d_len1 = (uint32_t *) (d_reads2 + words);     // caller reserves one extra word for the length
     HIPCHK(hipMemcpyAsync(d_len1, &len, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(pack2bit_kernel, dim3(cpr), dim3(256), 0, stream, d_read, (uint64_t) 0, d_len1,
