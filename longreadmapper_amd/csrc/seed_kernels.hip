@@ -374,19 +374,22 @@ __device__ __forceinline__ bool vote_admit(const VoteTable &t, uint64_t key, uin
     return true;
 }
 
-// Repeat seeds (rr > 4): the hits of one seed are a contiguous run of SA rows, read by the whole
-// wavefront at once; the first 64 rows of up to four such seeds are in flight together.
+// Repeat seeds (rr > 4): the hits of one seed are a contiguous run of SA rows, read by the whole wavefront.
 
+// BIG_GRP seeds at a time, and for each of them the next BIG_U x 64 SA rows: all gathers of a group are issued
+// before its first vote, so a repeat seed with up to 320 hits costs ONE memory latency instead of five.
+#define BIG_GRP 2
+#define BIG_U 5
 __device__ __forceinline__ bool vote_big_seeds(const LrmIndexView &ix, const VoteTable &t, uint32_t rr, uint64_t k,
                                                uint32_t q0, uint32_t iter, uint32_t P, uint32_t tbits, int lane,
                                                uint32_t passes, uint32_t pass) {
     bool ok = true;
     unsigned long long big = __ballot(rr > 4);
     while (big) {
-        uint32_t rs[4], qs[4];
-        uint64_t ks[4], js[4], v[4];
+        uint32_t rs[BIG_GRP], qs[BIG_GRP];
+        uint64_t ks[BIG_GRP], js[BIG_GRP];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < BIG_GRP; ++g) {
             rs[g] = 0; qs[g] = 0; ks[g] = 0; js[g] = 0;
             if (big) {
                 const int src = __builtin_ctzll(big);
@@ -399,15 +402,26 @@ __device__ __forceinline__ bool vote_big_seeds(const LrmIndexView &ix, const Vot
                 js[g] = (uint64_t) iter + (uint64_t) qs[g] * (uint64_t) P;
             }
         }
+        uint32_t rmax = rs[0];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) v[g] = (uint32_t) lane < rs[g] ? ix.sa[ks[g] + (uint32_t) lane] : 0ull;
+        for (int g = 1; g < BIG_GRP; ++g) rmax = rs[g] > rmax ? rs[g] : rmax;
+        for (uint32_t base = 0; base < rmax; base += 64 * BIG_U) {        // one trip unless thres > 320
+            uint64_t v[BIG_GRP][BIG_U];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            if ((uint32_t) lane < rs[g]) ok &= vote_admit(t, v[g] - js[g], (qs[g] << tbits) | (uint32_t) lane, passes, pass);
+            for (int g = 0; g < BIG_GRP; ++g)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            for (uint32_t tt = (uint32_t) lane + 64; tt < rs[g]; tt += 64)
-                ok &= vote_admit(t, ix.sa[ks[g] + tt] - js[g], (qs[g] << tbits) | tt, passes, pass);
+                for (int u = 0; u < BIG_U; ++u) {
+                    const uint32_t tt = base + (uint32_t) u * 64 + (uint32_t) lane;
+                    v[g][u] = tt < rs[g] ? ix.sa[ks[g] + tt] : 0ull;
+                }
+#pragma unroll
+            for (int g = 0; g < BIG_GRP; ++g)
+#pragma unroll
+                for (int u = 0; u < BIG_U; ++u) {
+                    const uint32_t tt = base + (uint32_t) u * 64 + (uint32_t) lane;
+                    if (tt < rs[g]) ok &= vote_admit(t, v[g][u] - js[g], (qs[g] << tbits) | tt, passes, pass);
+                }
+        }
     }
     return ok;
 }
