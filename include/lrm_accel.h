@@ -15,8 +15,11 @@
  *     sa_access fmidx.h:30, histo_* histo.h:32-37
  *   PART 2 locus resolve + rev-comp + extension,                lrm_extend_batch
  *     alnmain.c:408-451, cigar_align mutils.h:57-58
+ *   PART 1 + PART 2 in one device pass (one upload per batch)   lrm_map_batch
  *   PART 3 result flags, alnmain.c:458-477                      lrm_result_flags
  *   context_destroy(), accaln.c:7-43                            lrm_index_free
+ *   host batch loop over devices, alnmain.c:302-330             lrm_index_upload_multi (+ the same batch calls)
+ *   pair_end(), alnmain.c:554-557 (unimplemented, returns -1)   lrm_pair_end
  *
  * Struct mirrors keep the reference's field order so the reference's own
  * objects can be passed by pointer cast (dna_fmi*, lc_hash*, entry*, params).
@@ -38,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LRM_ABI_VERSION 1
+#define LRM_ABI_VERSION 2
 
 /* histo/histo.h:21-23 `entry` */
 typedef struct lrm_entry { uint64_t key, val, bucket; } lrm_entry;
@@ -107,6 +110,19 @@ int lrm_index_upload(lrm_index **out, const lrm_dna_fmi *fmi, const lrm_lc_hash 
                      const lrm_sa_mem *sa, const char *content, uint64_t con_len,
                      const lrm_mta_entry *mta, int mta_len, int device);
 
+/* Multi-GPU group: the image is packed once, uploaded to devices[0] and replicated to the other devices over
+ * xGMI (one RCCL broadcast; hipMemcpyPeer if librccl cannot be loaded).  devices == NULL means 0..ngpus-1.  The
+ * returned handle is used with the same batch calls: lrm_seed_batch / lrm_extend_batch / lrm_map_batch split
+ * the batch into ngpus contiguous slices balanced by bases and run one host thread per device, every device
+ * writing its slice of the caller's arrays in place (results do not depend on ngpus).  A device may be listed
+ * more than once (logical replicas on one GPU).  The *_dev entry points address one replica:
+ * lrm_index_replica(). */
+int lrm_index_upload_multi(lrm_index **out, const lrm_dna_fmi *fmi, const lrm_lc_hash *lch,
+                           const lrm_sa_mem *sa, const char *content, uint64_t con_len,
+                           const lrm_mta_entry *mta, int mta_len, const int *devices, int ngpus);
+int lrm_index_replicas(const lrm_index *idx);
+lrm_index *lrm_index_replica(lrm_index *idx, int r);     /* borrowed; replica 0 is the handle itself */
+
 /* Adopt a blob that already sits in device memory (e.g. the destination of an
  * RCCL broadcast).  The blob is borrowed: it must outlive the handle. */
 int lrm_index_adopt_device(lrm_index **out, void *d_blob, uint64_t blob_bytes, int device);
@@ -136,6 +152,25 @@ int lrm_extend_batch(lrm_index *idx, char *reads_buf, uint64_t stride,
                      uint64_t store_stride, int *score_out, lrm_seq_meta *meta_out,
                      int *meta_r_out);
 
+/* PART 1 + PART 2 for one batch in a single device pass: the reads cross the link once, best[] stays on the
+ * device between the two parts.  Same outputs as lrm_seed_batch followed by lrm_extend_batch. */
+int lrm_map_batch(lrm_index *idx, char *reads_buf, uint64_t stride, const uint32_t *lens, uint64_t n,
+                  lrm_params p, lrm_gact_params gp, lrm_entry *best_out, lrm_cigar *cig_out,
+                  uint8_t *store_mem, uint64_t store_stride, int *score_out, lrm_seq_meta *meta_out,
+                  int *meta_r_out);
+
+/* Pinned host memory for the batch buffers (reads_buf, store_mem): the DMA engines then read / write the
+ * caller's memory directly; pageable buffers work too and are staged through pinned chunks.
+ * lrm_host_register pins memory the caller already owns (what alnmain.c:297-320 mallocs). */
+void *lrm_host_alloc(uint64_t bytes);
+void lrm_host_free(void *p);
+int lrm_host_register(void *p, uint64_t bytes);
+int lrm_host_unregister(void *p);
+
+/* alnmain.c:554-557 `pair_end`: declared, unimplemented ("todo") and returning -1 in the reference; kept so
+ * that the call surface is complete. */
+int lrm_pair_end(int argc, const char *argv[]);
+
 /* PART 3 flag/mapq/valid assembly (alnmain.c:460-474); pure host arithmetic. */
 void lrm_result_flags(const int *score, const int *meta_r, const lrm_seq_meta *meta,
                       uint64_t n, int *flag_out, int *mapq_out, int *valid_out);
@@ -147,7 +182,10 @@ void lrm_result_flags(const int *score, const int *meta_r, const lrm_seq_meta *m
 
 typedef struct lrm_workspace lrm_workspace;   /* opaque: device scratch for a batch shape */
 
-/* Scratch for batches of up to n_max reads of up to max_len bases. */
+/* Scratch for batches of up to n_max reads of up to max_len bases.
+ * Preconditions of the *_dev calls (not checked on the device): d_lens[i] <= max_len <= stride, and
+ * store_stride >= 2*max_len.  A kernel-side error of a batch (vote table overflow) is sticky: the NEXT *_dev
+ * call on the workspace, or lrm_workspace_stats, returns -2 and clears it. */
 int lrm_workspace_create(lrm_workspace **out, lrm_index *idx, uint64_t n_max,
                          uint32_t max_len, uint32_t seed_len, uint32_t thres);
 void lrm_workspace_free(lrm_workspace *ws);

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 
-ACCEL_SRCS = ["lrm_api.hip", "seed_kernels.hip", "gact_kernels.hip", "gact_bs_kernels.hip", "index_host.cpp", "io_host.cpp"]
+ACCEL_SRCS = ["lrm_api.hip", "lrm_host.hip", "seed_kernels.hip", "gact_kernels.hip", "gact_bs_kernels.hip", "index_host.cpp", "io_host.cpp"]
 ACCEL_DEPS = ACCEL_SRCS + ["lrm_internal.h", "../../include/lrm_accel.h", "../../include/lrm_index_host.h",
                            "../../include/lrm_io_host.h"]
 ACCEL_LIB = os.path.join(HERE, "liblrm_accel.so")
@@ -53,7 +53,7 @@ def build_accel(force=False):
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fopenmp",
            "-I" + os.path.join(ROOT, "include")]
     cmd += [os.path.join(CSRC, s) for s in ACCEL_SRCS]
-    cmd += ["-lz", "-o", ACCEL_LIB]
+    cmd += ["-lz", "-ldl", "-o", ACCEL_LIB]
     _run(cmd)
     return ACCEL_LIB
 

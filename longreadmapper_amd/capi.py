@@ -92,6 +92,18 @@ SYMBOLS = {
     "lrm_extend_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                    GactParams, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
+    "lrm_map_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, Params, GactParams,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lrm_host_alloc": (C.c_void_p, [C.c_uint64]),
+    "lrm_host_free": (None, [C.c_void_p]),
+    "lrm_host_register": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "lrm_host_unregister": (C.c_int, [C.c_void_p]),
+    "lrm_pair_end": (C.c_int, [C.c_int, C.c_void_p]),
+    "lrm_index_upload_multi": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(DnaFmi), C.POINTER(LcHash),
+                                         C.POINTER(SaMem), C.c_void_p, C.c_uint64, C.POINTER(MtaEntry), C.c_int,
+                                         C.POINTER(C.c_int), C.c_int]),
+    "lrm_index_replicas": (C.c_int, [C.c_void_p]),
+    "lrm_index_replica": (C.c_void_p, [C.c_void_p, C.c_int]),
     "lrm_result_flags": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lrm_workspace_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                        C.c_uint32]),

@@ -588,13 +588,17 @@ int lrm_bs_prepare_index(lrm_index *idx) {
     const uint64_t words = lrm_bs_planar_words(len), groups = (len + 63) / 64;
     uint64_t *d = nullptr;
     uint32_t *flag = nullptr;
-    HIPCHK(hipMalloc(&d, words * 8 + 16));
-    HIPCHK(hipMalloc(&flag, 16));
     (void) groups;
-    if (lrm_bs_pack_text(idx->view.content, len, d, flag, nullptr)) return -1;
     uint32_t h = 0;
-    HIPCHK(hipMemcpy(&h, flag, 4, hipMemcpyDeviceToHost));
-    (void) hipFree(flag);
+    const bool ok = hipMalloc(&d, words * 8 + 16) == hipSuccess && hipMalloc(&flag, 16) == hipSuccess &&
+                    lrm_bs_pack_text(idx->view.content, len, d, flag, nullptr) == 0 &&
+                    hipMemcpy(&h, flag, 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if (flag) (void) hipFree(flag);
+    if (!ok) {                                   // nothing leaks on a failed allocation / pack / copy
+        if (d) (void) hipFree(d);
+        lrm_set_error("planar text for the bit-sliced extension: %s", hipGetErrorString(hipGetLastError()));
+        return -1;
+    }
     idx->d_cpl = d;
     idx->cpl_ok = h == 0;          // a text with bytes other than ACGT keeps the byte kernels
     return 0;

@@ -440,8 +440,7 @@ __global__ __launch_bounds__(256) void gact3_kernel(const char *__restrict__ rea
                                                     const uint32_t *__restrict__ tlens, uint64_t n_reads,
                                                     int T, int O, int W, uint8_t *__restrict__ store,
                                                     uint64_t store_stride, int32_t *__restrict__ n_ops_out,
-                                                    int32_t *__restrict__ score_out, LrmDevCounters *counters,
-                                                    int dbg) {
+                                                    int32_t *__restrict__ score_out, LrmDevCounters *counters) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
@@ -516,7 +515,6 @@ __global__ __launch_bounds__(256) void gact3_kernel(const char *__restrict__ rea
         const uint32_t eO = pack16(min(2 * tq[0] + dO, 2 * tt[0] - dO), min(2 * tq[1] + dO, 2 * tt[1] - dO));
         uint32_t r1 = 0, r2 = 0, accN = 0, accG = 0;
         int s = max(tq[0] + tt[0], tq[1] + tt[1]);
-        if (dbg & 1) s = 1;
         const uint32_t *qp, *dp;
         uint32_t qc = 0, dc = 0, qn, dn;
         if ((s & 1) == 0) {
@@ -599,11 +597,6 @@ __global__ __launch_bounds__(256) void gact3_kernel(const char *__restrict__ rea
             const int sh = 16 * h;
             int a = 0, b = 0, cnt = 0, sc = 0;
             uint8_t *out = ops_out[h] + nops[h];
-            if (dbg & 2) {
-                a = b = min(min(tq[h], tt[h]), cap);
-                i[h] += a; j[h] += b;
-                continue;
-            }
             while (a < tq[h] && b < tt[h] && (last[h] ? (a + b < lim2) : (a < cap && b < cap))) {
                 const int sw = a + b, dd = b - a, e0 = sw & 15;
                 uint32_t n0 = 0, g0 = 0, n1 = 0, g1 = 0;
@@ -813,7 +806,7 @@ typedef void (*gact1_fn_t)(const char *, uint64_t, const uint32_t *, const lrm_s
                            int32_t *, LrmDevCounters *, const uint32_t *);
 typedef void (*gact2_fn_t)(const char *, uint64_t, const uint32_t *, const lrm_seq_meta *, const int32_t *,
                            const char *, const uint32_t *, uint64_t, int, int, int, uint8_t *, uint64_t, int32_t *,
-                           int32_t *, LrmDevCounters *, int);
+                           int32_t *, LrmDevCounters *);
 
 static int gact_launch(lrm_gact_params gp, uint64_t n, hipStream_t stream, const char *reads, uint64_t stride,
                        const uint32_t *lens, const lrm_seq_meta *meta, const int32_t *meta_r, const char *content,
@@ -842,8 +835,6 @@ static int gact_launch(lrm_gact_params gp, uint64_t n, hipStream_t stream, const
     // text, 4-byte aligned CIGAR store; otherwise as 0)
     int impl = 0;
     { const char *e = getenv("LRM_GACT_IMPL"); impl = e ? atoi(e) : 0; }
-    static int dbg3 = -1;
-    if (dbg3 < 0) { const char *e = getenv("LRM_GACT_DBG"); dbg3 = e ? atoi(e) : 0; }
     const int nblk = ((2 * (gp.T - gp.O) - 1) >> 4) + 1;
     // Bit-sliced kernel: a wavefront carries 64 reads, so it needs a large batch to fill the chip
     // (below ~16 k reads the two-reads-per-wavefront kernel finishes first).
@@ -871,7 +862,7 @@ static int gact_launch(lrm_gact_params gp, uint64_t n, hipStream_t stream, const
         else fn3 = gp.W >= 128 ? gact3_kernel<true, 32> : gact3_kernel<false, 32>;
         uint64_t blocks3 = (n + 7) / 8;
         hipLaunchKernelGGL(fn3, dim3((uint32_t) blocks3), dim3(256), shmem3, stream, reads, stride, lens, meta, meta_r,
-                           content, tlens, n, gp.T, gp.O, gp.W, store, store_stride, n_ops, score, counters, dbg3);
+                           content, tlens, n, gp.T, gp.O, gp.W, store, store_stride, n_ops, score, counters);
         return 0;
     }
     GactLds L = gact_lds_layout(gp.T, gp.O);
@@ -962,19 +953,21 @@ extern "C" int lrm_debug_gact(const char *q, int n, const char *d, int m, lrm_ga
         lrm_set_error("unsupported GACT parameters T=%d O=%d W=%d", gp.T, gp.O, gp.W);
         return -1;
     }
-    char *dq = nullptr, *dd = nullptr;
-    uint8_t *dops = nullptr;
-    uint32_t *dl = nullptr;
-    lrm_seq_meta *dm = nullptr;
-    int32_t *dr = nullptr;
-    LrmDevCounters *dc = nullptr;
-    HIPCHK(hipMalloc(&dq, (size_t) n + 16));
-    HIPCHK(hipMalloc(&dd, (size_t) m + 16));
-    HIPCHK(hipMalloc(&dops, (size_t) n + m + 16));
-    HIPCHK(hipMalloc(&dl, 16));
-    HIPCHK(hipMalloc(&dm, sizeof(lrm_seq_meta)));
-    HIPCHK(hipMalloc(&dr, 16));
-    HIPCHK(hipMalloc(&dc, sizeof(LrmDevCounters)));
+    // every device buffer is owned by a guard: an early HIPCHK return frees them all
+    struct Buf {
+        void *p = nullptr;
+        ~Buf() { if (p) (void) hipFree(p); }
+        int alloc(size_t bytes) { return hipMalloc(&p, bytes) == hipSuccess ? 0 : -1; }
+    };
+    Buf bq, bd, bops, bl, bm, br, bc, bqpl, bcpl, bfl, bcodes, bck;
+    if (bq.alloc((size_t) n + 16) || bd.alloc((size_t) m + 16) || bops.alloc((size_t) n + m + 16) || bl.alloc(16) ||
+        bm.alloc(sizeof(lrm_seq_meta)) || br.alloc(16) || bc.alloc(sizeof(LrmDevCounters))) { lrm_set_error("device allocation failed"); return -1; }
+    char *dq = (char *) bq.p, *dd = (char *) bd.p;
+    uint8_t *dops = (uint8_t *) bops.p;
+    uint32_t *dl = (uint32_t *) bl.p;
+    lrm_seq_meta *dm = (lrm_seq_meta *) bm.p;
+    int32_t *dr = (int32_t *) br.p;
+    LrmDevCounters *dc = (LrmDevCounters *) bc.p;
     HIPCHK(hipMemset(dc, 0, sizeof(LrmDevCounters)));
     uint32_t hl[2] = {(uint32_t) n, (uint32_t) m};
     lrm_seq_meta hm; hm.loc = 0; hm.off = 0; hm.seq_id = 0; hm.strand = 0;
@@ -985,22 +978,18 @@ extern "C" int lrm_debug_gact(const char *q, int n, const char *d, int m, lrm_ga
     HIPCHK(hipMemcpy(dm, &hm, sizeof(hm), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dr, hr, 12, hipMemcpyHostToDevice));
     LrmBsArgs bs = {};
-    uint64_t *dqpl = nullptr, *dcpl = nullptr, *dcodes = nullptr;
-    uint32_t *dfl = nullptr, *dck = nullptr;
     if (lrm_bs_wanted(gp, 1)) {
         const uint64_t wq = lrm_bs_planar_words((uint64_t) n), wd = lrm_bs_planar_words((uint64_t) m);
-        HIPCHK(hipMalloc(&dqpl, wq * 8 + 16));
-        HIPCHK(hipMalloc(&dcpl, wd * 8 + 16));
-        HIPCHK(hipMalloc(&dfl, 16));
-        if (lrm_bs_pack_text(dd, (uint64_t) m, dcpl, dfl + 1, nullptr)) return -1;
-        if (lrm_bs_pack_reads(dq, 0, dl, 1, (uint32_t) n, dqpl, wq, dfl, nullptr)) return -1;
+        bs.cw = lrm_bs_code_words((uint32_t) (n > m ? n : m));
+        if (bqpl.alloc(wq * 8 + 16) || bcpl.alloc(wd * 8 + 16) || bfl.alloc(16) || bcodes.alloc(bs.cw * 8 + 16) ||
+            bck.alloc(lrm_bs_ckpt_words(1) * 4)) { lrm_set_error("device allocation failed"); return -1; }
+        uint32_t *dfl = (uint32_t *) bfl.p;
+        if (lrm_bs_pack_text(dd, (uint64_t) m, (uint64_t *) bcpl.p, dfl + 1, nullptr)) return -1;
+        if (lrm_bs_pack_reads(dq, 0, dl, 1, (uint32_t) n, (uint64_t *) bqpl.p, wq, dfl, nullptr)) return -1;
         uint32_t tf = 0;
         HIPCHK(hipMemcpy(&tf, dfl + 1, 4, hipMemcpyDeviceToHost));
-        bs.qpl = dqpl; bs.wpr = wq; bs.flags = dfl; bs.cpl = tf ? nullptr : dcpl;
-        bs.cw = lrm_bs_code_words((uint32_t) (n > m ? n : m));
-        HIPCHK(hipMalloc(&dcodes, bs.cw * 8 + 16));
-        HIPCHK(hipMalloc(&dck, lrm_bs_ckpt_words(1) * 4));
-        bs.codes = dcodes; bs.ckpt = dck; bs.ncodes = (int32_t *) (dfl + 2);
+        bs.qpl = (uint64_t *) bqpl.p; bs.wpr = wq; bs.flags = dfl; bs.cpl = tf ? nullptr : (uint64_t *) bcpl.p;
+        bs.codes = (uint64_t *) bcodes.p; bs.ckpt = (uint32_t *) bck.p; bs.ncodes = (int32_t *) (dfl + 2);
     }
     if (gact_launch(gp, 1, 0, dq, 0, dl, dm, dr, dd, dl + 1, dops, 0, dr + 1, dr + 2, dc, bs.qpl ? &bs : nullptr)) return -1;
     HIPCHK(hipGetLastError());
@@ -1009,12 +998,5 @@ extern "C" int lrm_debug_gact(const char *q, int n, const char *d, int m, lrm_ga
     *n_ops = hr[1];
     *score = hr[2];
     if (hr[1] > 0) HIPCHK(hipMemcpy(ops, dops, (size_t) hr[1], hipMemcpyDeviceToHost));
-    (void) hipFree(dq); (void) hipFree(dd); (void) hipFree(dops); (void) hipFree(dl);
-    (void) hipFree(dm); (void) hipFree(dr); (void) hipFree(dc);
-    if (dqpl) (void) hipFree(dqpl);
-    if (dcpl) (void) hipFree(dcpl);
-    if (dfl) (void) hipFree(dfl);
-    if (dcodes) (void) hipFree(dcodes);
-    if (dck) (void) hipFree(dck);
     return 0;
 }

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 #include <omp.h>
@@ -17,6 +18,13 @@
 // construction").  s[n-1] must be the unique smallest symbol.
 // ------------------------------------------------------------------------------------------
 namespace {
+
+// LRM_BUILD_VERBOSE=1: stage times of the index builder on stderr
+struct StageTimer {
+    double t0; bool on;
+    StageTimer() : t0(omp_get_wtime()), on(getenv("LRM_BUILD_VERBOSE") != nullptr) {}
+    void lap(const char *what) { if (on) { const double t = omp_get_wtime(); fprintf(stderr, "[lrm build] %-28s %8.2f s\n", what, t - t0); t0 = t; } }
+};
 
 template <typename I>
 struct SaIs {
@@ -118,9 +126,241 @@ inline uint64_t splitmix64(uint64_t &s) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------
+// Parallel suffix sorter for nucleotide texts (the builder GRCh38-sized references need: 6.2 G rows in
+// minutes on the host cores next to the GPU; the reference uses the parallel external-memory pSAscan,
+// psascan/sa_use.cc:8-18, asindex.c:138).  The suffix array of a text that ends in a unique minimal '$' is
+// unique, so any correct sorter reproduces the reference's .sa5 byte for byte.
+//
+//   1. the text is packed to 2 bits per base, first base most significant, so that the integer order of a
+//      64-bit window is the lexicographic order of 32 bases; positions past the last base read as 'A' (0)
+//   2. suffixes are distributed by their first PB bases into 4^PB buckets (histogram, prefix sums)
+//   3. the buckets are processed in groups that fit a bounded scratch: one parallel scan of the text collects
+//      {next 32 bases, position} of every suffix of the group, each bucket is sorted by that key in cache,
+//      and only runs of equal keys (40+ common bases) are compared through the packed text
+//   4. the sorted positions go straight into the caller's ui40 array (8-byte slots, padding zeroed)
+// A suffix that runs into '$' compares as if padded with 'A' and loses ties to longer suffixes, which is the
+// order '$' < 'A' gives.  Texts with very long exact repeats would make step 3 quadratic: the work spent on
+// ties is counted and the build falls back to the linear-time SA-IS above when it exceeds a budget.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct PackedText {
+    std::vector<uint64_t> w;      // 32 bases per word, first base in bits 63..62
+    uint64_t n = 0;               // bases (text length without '$')
+    inline uint64_t window(uint64_t p) const {             // bases p .. p+31, zero padded
+        const uint64_t i = p >> 5, sh = (p & 31) * 2;
+        const uint64_t a = w[i], b = w[i + 1];
+        return sh ? ((a << sh) | (b >> (64 - sh))) : a;
+    }
+    inline uint64_t roll(uint64_t win, uint64_t p) const {  // window(p) -> window(p + 1)
+        const uint64_t q = p + 32;
+        return (win << 2) | ((w[q >> 5] >> (62 - 2 * (q & 31))) & 3ull);
+    }
+};
+
+struct KeyPos { uint64_t key, pos; };
+
+// exact order of the suffixes at p and q, known to share their first d bases (padded semantics, see above)
+static inline bool suffix_less(const PackedText &t, uint64_t p, uint64_t q, uint64_t d, uint64_t &work) {
+    while (true) {
+        const int64_t lp = (int64_t) t.n - (int64_t) (p + d), lq = (int64_t) t.n - (int64_t) (q + d);
+        if (lp <= 0 || lq <= 0) return p > q;                        // the one that has reached '$' is smaller
+        const uint64_t wp = t.window(p + d), wq = t.window(q + d);
+        ++work;
+        if (wp != wq) {
+            const int64_t first = __builtin_clzll(wp ^ wq) >> 1, lmin = lp < lq ? lp : lq;
+            if (first >= lmin) return p > q;                          // equal up to the shorter one's '$'
+            return wp < wq;
+        }
+        d += 32;
+    }
+}
+
+template <typename F>
+static void sort_ties(KeyPos *a, uint64_t n, F less) {
+    for (uint64_t i = 0; i < n;) {
+        uint64_t j = i + 1;
+        while (j < n && a[j].key == a[i].key) ++j;
+        if (j - i > 1) std::sort(a + i, a + j, less);
+        i = j;
+    }
+}
+
+// 2-bit image of text[0 .. L-1) (the '$' at L-1 is not part of it); false if the text holds a byte other than
+// upper-case ACGT (such texts take the generic paths)
+static bool pack_text(const char *text, uint64_t L, PackedText &t) {
+    const uint64_t n = L - 1;
+    t.n = n;
+    t.w.assign(n / 32 + 4, 0);
+    int bad = 0;
+    const uint64_t nwords = (n + 31) / 32;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+    for (uint64_t wi = 0; wi < nwords; ++wi) {
+        uint64_t v = 0;
+        const uint64_t lo = wi * 32, hi = lo + 32 < n ? lo + 32 : n;
+        for (uint64_t i = lo; i < hi; ++i) {
+            const int c = dna_code(text[i]);
+            if (c < 0 || text[i] > 'Z') bad = 1;
+            v |= (uint64_t) (c & 3) << (62 - 2 * (i - lo));
+        }
+        t.w[wi] = v;
+    }
+    return !bad;
+}
+
+// top-bits distribution + std::sort of the pieces: ~3x fewer comparisons than std::sort alone on a 100 k-row bucket
+static void sort_by_key(KeyPos *a, uint64_t m, std::vector<KeyPos> &tmp) {
+    auto by_key = [](const KeyPos &x, const KeyPos &y) { return x.key < y.key; };
+    if (m < 2048) { std::sort(a, a + m, by_key); return; }
+    constexpr int RB = 11;
+    uint32_t cnt[(1u << RB) + 1] = {0};
+    for (uint64_t i = 0; i < m; ++i) cnt[(a[i].key >> (64 - RB)) + 1]++;
+    for (uint32_t b = 0; b < (1u << RB); ++b) cnt[b + 1] += cnt[b];
+    if (tmp.size() < m) tmp.resize(m);
+    uint32_t cur[1u << RB];
+    memcpy(cur, cnt, sizeof(cur));
+    for (uint64_t i = 0; i < m; ++i) tmp[cur[a[i].key >> (64 - RB)]++] = a[i];
+    memcpy(a, tmp.data(), m * sizeof(KeyPos));
+    for (uint32_t b = 0; b < (1u << RB); ++b)
+        if (cnt[b + 1] - cnt[b] > 1) std::sort(a + cnt[b], a + cnt[b + 1], by_key);
+}
+
+static int sa_build_bucketed(const PackedText &t, uint64_t L, lrm_ui40 *out, uint64_t tie_budget_per_row) {
+    const uint64_t n = L - 1;
+    StageTimer tm;
+
+    const int PB = L > (1ull << 26) ? 8 : (L > (1ull << 18) ? 5 : 2);     // bases of the distribution prefix
+    const uint64_t NB = 1ull << (2 * PB);
+    const int nth = omp_get_max_threads();
+    // histogram of prefixes (per-thread, merged)
+    std::vector<uint64_t> cnt(NB + 1, 0);
+    {
+        std::vector<std::vector<uint64_t>> local((size_t) nth, std::vector<uint64_t>(NB, 0));
+#pragma omp parallel
+        {
+            std::vector<uint64_t> &h = local[(size_t) omp_get_thread_num()];
+#pragma omp for schedule(static)
+            for (uint64_t blk = 0; blk < (n + 65535) / 65536; ++blk) {
+                const uint64_t lo = blk * 65536, hi = lo + 65536 < n ? lo + 65536 : n;
+                uint64_t win = t.window(lo);
+                for (uint64_t p = lo; p < hi; ++p) {
+                    h[win >> (64 - 2 * PB)]++;
+                    win = t.roll(win, p);
+                }
+            }
+        }
+        for (int th = 0; th < nth; ++th) for (uint64_t bkt = 0; bkt < NB; ++bkt) cnt[bkt + 1] += local[(size_t) th][bkt];
+    }
+    for (uint64_t bkt = 0; bkt < NB; ++bkt) cnt[bkt + 1] += cnt[bkt];      // cnt[b] = suffixes in buckets < b
+    tm.lap("sa: prefix histogram");
+    uint64_t *sa64 = reinterpret_cast<uint64_t *>(out);                    // a ui40 slot is 8 bytes: value < 2^40, padding 0
+    sa64[0] = n;                                                           // the suffix "$"
+
+    // groups of consecutive buckets within the scratch bound
+    uint64_t scratch_rows = (L / 6) + (1ull << 20);
+    if (const char *e = getenv("LRM_SA_SCRATCH_ROWS")) { const long long v = atoll(e); if (v >= 1024) scratch_rows = (uint64_t) v; }   // test knob
+    uint64_t max_bucket = 0;
+    for (uint64_t bkt = 0; bkt < NB; ++bkt) max_bucket = std::max(max_bucket, cnt[bkt + 1] - cnt[bkt]);
+    if (scratch_rows < max_bucket) scratch_rows = max_bucket;
+    KeyPos *scratch = (KeyPos *) malloc(scratch_rows * sizeof(KeyPos));
+    if (!scratch) { lrm_set_error("out of memory (suffix sorter scratch, %llu rows)", (unsigned long long) scratch_rows); return -1; }
+    std::vector<uint64_t> cursor(NB);
+    uint64_t work_total = 0;
+    const uint64_t budget = tie_budget_per_row * L + (1ull << 24);
+    bool over = false;
+    for (uint64_t g0 = 0; g0 < NB && !over;) {
+        uint64_t g1 = g0 + 1;
+        while (g1 < NB && cnt[g1 + 1] - cnt[g0] <= scratch_rows) ++g1;
+        const uint64_t base = cnt[g0], rows = cnt[g1] - cnt[g0];
+        if (rows == 0) { g0 = g1; continue; }
+        for (uint64_t bkt = g0; bkt < g1; ++bkt) cursor[bkt] = cnt[bkt] - base;
+        // collect {key, position} of the group's suffixes: threads reserve space in small batches
+#pragma omp parallel
+        {
+            constexpr int LB = 8;
+            std::vector<KeyPos> lbuf((size_t) (g1 - g0) * LB);
+            std::vector<uint8_t> lcnt((size_t) (g1 - g0), 0);
+            auto flush = [&](uint64_t bkt) {
+                const uint64_t k = bkt - g0;
+                const uint8_t m = lcnt[k];
+                if (!m) return;
+                uint64_t at;
+#pragma omp atomic capture
+                { at = cursor[bkt]; cursor[bkt] += m; }
+                memcpy(scratch + at, &lbuf[k * LB], (size_t) m * sizeof(KeyPos));
+                lcnt[k] = 0;
+            };
+#pragma omp for schedule(dynamic, 4) nowait
+            for (uint64_t blk = 0; blk < (n + 262143) / 262144; ++blk) {
+                const uint64_t lo = blk * 262144, hi = lo + 262144 < n ? lo + 262144 : n;
+                uint64_t win = t.window(lo);
+                for (uint64_t p = lo; p < hi; ++p) {
+                    const uint64_t bkt = win >> (64 - 2 * PB);
+                    win = t.roll(win, p);
+                    if (bkt < g0 || bkt >= g1) continue;
+                    const uint64_t k = bkt - g0;
+                    lbuf[k * LB + lcnt[k]] = KeyPos{t.window(p + (uint64_t) PB), p};
+                    if (++lcnt[k] == LB) flush(bkt);
+                }
+            }
+            for (uint64_t bkt = g0; bkt < g1; ++bkt) flush(bkt);
+        }
+        tm.lap("sa: collect group");
+        // sort every bucket: by key in cache, ties through the text
+        uint64_t work = 0;
+#pragma omp parallel reduction(+ : work)
+        {
+        std::vector<KeyPos> tmp;
+#pragma omp for schedule(dynamic, 1)
+        for (uint64_t bkt = g0; bkt < g1; ++bkt) {
+            KeyPos *a = scratch + (cnt[bkt] - base);
+            const uint64_t m = cnt[bkt + 1] - cnt[bkt];
+            if (m == 0) continue;
+            sort_by_key(a, m, tmp);
+            uint64_t wk = 0;
+            sort_ties(a, m, [&](const KeyPos &x, const KeyPos &y) { return suffix_less(t, x.pos, y.pos, (uint64_t) PB + 32, wk); });
+            work += wk;
+            uint64_t *dst = sa64 + 1 + cnt[bkt];
+            for (uint64_t i = 0; i < m; ++i) dst[i] = a[i].pos;
+        }
+        }
+        work_total += work;
+        tm.lap("sa: sort group");
+        if (work_total > budget) over = true;
+        g0 = g1;
+    }
+    free(scratch);
+    return over ? 1 : 0;           // 1: too repetitive for this scheme, the caller falls back to SA-IS
+}
+
+}  // namespace
+
+static thread_local const PackedText *g_packed_for_build = nullptr;
+
+// LRM_SA_ALGO = "sais" forces the linear-time sorter, "bucket" the parallel one (no fallback budget).
 extern "C" int lrm_sa_build(const char *text, uint64_t L, lrm_ui40 *out) {
     if (!text || !out || L < 1) { lrm_set_error("bad argument"); return -1; }
     if (text[L - 1] != '$') { lrm_set_error("text must end in '$'"); return -1; }
+    {   // '$' must not occur inside the text
+        uint64_t inner = ~0ull;
+#pragma omp parallel for schedule(static) reduction(min : inner)
+        for (uint64_t i = 0; i < L - 1; ++i) if (text[i] == '$' && i < inner) inner = i;
+        if (inner != ~0ull) { lrm_set_error("'$' occurs inside the text (offset %llu)", (unsigned long long) inner); return -1; }
+    }
+    const char *algo = getenv("LRM_SA_ALGO");
+    const bool force_sais = algo && !strcmp(algo, "sais"), force_bucket = algo && !strcmp(algo, "bucket");
+    if (!force_sais && L >= 2) {
+        PackedText own;
+        const PackedText *t = g_packed_for_build;          // lrm_host_index_build shares its packed text
+        if (!t) { if (pack_text(text, L, own)) t = &own; }
+        if (t) {
+            const int rc = sa_build_bucketed(*t, L, out, force_bucket ? (1ull << 40) / (L ? L : 1) + 1024 : 24);
+            if (rc == 0) return 0;
+            if (rc < 0) return -1;
+        }
+        // bytes other than upper-case ACGT, or too repetitive: the generic linear-time path below
+    }
     // remap to a dense alphabet, '$' -> 0 (must be unique and last)
     std::vector<uint8_t> s((size_t) L);
     int map[256];
@@ -129,19 +369,18 @@ extern "C" int lrm_sa_build(const char *text, uint64_t L, lrm_ui40 *out) {
     int K = 0;
     for (int c = 0; c < 256; ++c) map[c] = seen[c] ? K++ : -1;
     if (map[(unsigned char) '$'] != 0) { lrm_set_error("'$' is not the smallest byte of the text"); return -1; }
+#pragma omp parallel for schedule(static)
     for (uint64_t i = 0; i < L; ++i) s[i] = (uint8_t) map[(unsigned char) text[i]];
-    for (uint64_t i = 0; i + 1 < L; ++i)
-        if (s[i] == 0) { lrm_set_error("'$' occurs inside the text (offset %llu)", (unsigned long long) i); return -1; }
+    uint64_t *sa64 = reinterpret_cast<uint64_t *>(out);          // ui40 slots are 8 bytes: value < 2^40, padding zeroed
     if (L < (1ull << 31) - 8) {
         std::vector<int32_t> sa((size_t) L);
         SaIs<int32_t>::run<uint8_t>(s.data(), sa.data(), (int32_t) L, (int32_t) (K - 1));
 #pragma omp parallel for schedule(static)
-        for (uint64_t i = 0; i < L; ++i) { out[i].low = (uint32_t) sa[i]; out[i].high = 0; }
+        for (uint64_t i = 0; i < L; ++i) sa64[i] = (uint64_t) (uint32_t) sa[i];
     } else {
-        std::vector<int64_t> sa((size_t) L);
-        SaIs<int64_t>::run<uint8_t>(s.data(), sa.data(), (int64_t) L, (int64_t) (K - 1));
-#pragma omp parallel for schedule(static)
-        for (uint64_t i = 0; i < L; ++i) { out[i].low = (uint32_t) (sa[i] & 0xffffffffll); out[i].high = (uint8_t) (sa[i] >> 32); }
+        // in place: SA-IS runs on the caller's 8-byte slots (int64), no second array
+        static_assert(sizeof(lrm_ui40) == 8, "ui40 is 8 bytes in RAM (sa_use.h:17-20)");
+        SaIs<int64_t>::run<uint8_t>(s.data(), reinterpret_cast<int64_t *>(out), (int64_t) L, (int64_t) (K - 1));
     }
     return 0;
 }
@@ -165,17 +404,24 @@ extern "C" int lrm_cat_from_seqs(const char *const *names, const char *const *se
         mta[i].name_own = 1;
         mta[i].offset = off;                          // asindex.c:89-93
         mta[i].seq_len = n;
+        // N/n -> pseudo-random base (asindex.c:53-60; seeded per position here, so the result does not depend on
+        // the thread count), upper-casing (asindex.c:63-68)
+        uint64_t bad_pos = ~0ull;
+        const uint64_t rs0 = splitmix64(rs);
+#pragma omp parallel for schedule(static) reduction(min : bad_pos)
         for (uint64_t p = 0; p < n; ++p) {
             char c = seqs[i][p];
-            if (c == 'n' || c == 'N') c = "ACGT"[splitmix64(rs) & 3];    // asindex.c:53-60 (seeded here)
-            if (c > 0x60) c -= 0x20;                  // asindex.c:63-68
-            if (dna_code(c) < 0) {
-                lrm_set_error("sequence %d offset %llu: byte 0x%02x is not a nucleotide", i, (unsigned long long) p, (unsigned) (unsigned char) c);
-                free(cat); lrm_mta_free(mta, nseq);
-                return -1;
-            }
+            if (c == 'n' || c == 'N') { uint64_t st = rs0 ^ (p * 0x9E3779B97F4A7C15ull); c = "ACGT"[splitmix64(st) & 3]; }
+            if (c > 0x60) c -= 0x20;
+            if (dna_code(c) < 0 && p < bad_pos) bad_pos = p;
             cat[off + p] = c;
         }
+        if (bad_pos != ~0ull) {
+            lrm_set_error("sequence %d offset %llu: byte 0x%02x is not a nucleotide", i, (unsigned long long) bad_pos, (unsigned) (unsigned char) seqs[i][bad_pos]);
+            free(cat); lrm_mta_free(mta, nseq);
+            return -1;
+        }
+#pragma omp parallel for schedule(static)
         for (uint64_t p = 0; p < n; ++p) cat[off + n + p] = "TGCA"[dna_code(cat[off + n - 1 - p])];   // asindex.c:70-75
         off += 2 * n;
     }
@@ -208,7 +454,11 @@ extern "C" int lrm_host_index_build(const char *cat, uint64_t L, const lrm_mta_e
     out->content = (char *) malloc(L + 1);
     out->sa.mem = (lrm_ui40 *) malloc(sizeof(lrm_ui40) * L);
     if (!out->content || !out->sa.mem) { lrm_host_index_free(out); lrm_set_error("out of memory"); return -1; }
-    memcpy(out->content, cat, L);
+    {
+        const uint64_t piece = 1ull << 22, np = (L + piece - 1) / piece;
+#pragma omp parallel for schedule(static)
+        for (uint64_t i = 0; i < np; ++i) memcpy(out->content + i * piece, cat + i * piece, L - i * piece < piece ? L - i * piece : piece);
+    }
     out->content[L] = 0;
     out->con_len = L;
     out->mta_len = mta_len;
@@ -220,38 +470,79 @@ extern "C" int lrm_host_index_build(const char *cat, uint64_t L, const lrm_mta_e
     }
     out->sa.start = 0;
     out->sa.len = L;
-    if (lrm_sa_build(cat, L, out->sa.mem)) { lrm_host_index_free(out); return -1; }
+    StageTimer tm;
+    PackedText pt;
+    const bool pure = pack_text(cat, L, pt);            // 2-bit image: a quarter of the footprint for the random accesses below
+    tm.lap("pack 2-bit");
+    g_packed_for_build = pure ? &pt : nullptr;
+    const int sa_rc = lrm_sa_build(cat, L, out->sa.mem);
+    g_packed_for_build = nullptr;
+    if (sa_rc) { lrm_host_index_free(out); return -1; }
+    tm.lap("suffix array");
     const lrm_ui40 *sa = out->sa.mem;
 
     lrm_dna_fmi *f = &out->fmi;
     // C table: counts over text[0..L-2], exclusive prefix sums over all byte values (fmidx.c:101-125)
     f->c = (uint64_t *) calloc(256, sizeof(uint64_t));
-    for (uint64_t i = 0; i + 1 < L; ++i) f->c[(unsigned char) cat[i]]++;
+    {
+        uint64_t ca = 0, cc = 0, cg = 0, ct = 0, other = 0;
+#pragma omp parallel for schedule(static) reduction(+ : ca, cc, cg, ct, other)
+        for (uint64_t i = 0; i < L - 1; ++i) {
+            switch (cat[i]) { case 'A': ca++; break; case 'C': cc++; break; case 'G': cg++; break; case 'T': ct++; break; default: other++; }
+        }
+        f->c[(unsigned char) 'A'] = ca; f->c[(unsigned char) 'C'] = cc; f->c[(unsigned char) 'G'] = cg; f->c[(unsigned char) 'T'] = ct;
+        if (other) {                                       // generic bytes: the plain loop
+            memset(f->c, 0, 256 * sizeof(uint64_t));
+            for (uint64_t i = 0; i + 1 < L; ++i) f->c[(unsigned char) cat[i]]++;
+        }
+    }
     { uint64_t sum = 0; for (int i = 0; i < 256; ++i) { uint64_t t = sum + f->c[i]; f->c[i] = sum; sum = t; } }
     // BWT (fmidx.c:76-98)
     f->length = L;
     f->bwt = (char *) malloc(L + 1);
 #pragma omp parallel for schedule(static)
-    for (uint64_t i = 0; i < L; ++i) { uint64_t v = ui40v(sa[i]); f->bwt[i] = v == 0 ? '$' : cat[v - 1]; }
+    for (uint64_t i = 0; i < L; ++i) {
+        const uint64_t v = ui40v(sa[i]);
+        f->bwt[i] = v == 0 ? '$' : (pure ? "ACGT"[(pt.w[(v - 1) >> 5] >> (62 - 2 * ((v - 1) & 31))) & 3] : cat[v - 1]);
+    }
     f->bwt[L] = 0;
+    tm.lap("C + bwt");
     // O table (fmidx.c:128-150,186-190)
     f->o_ratio = o_ratio;
     f->o_len = 4 * (L / (uint64_t) o_ratio + 1);
     f->o = (uint64_t *) calloc(f->o_len, sizeof(uint64_t));
-    {
-        uint64_t run[4] = {0, 0, 0, 0};
-        for (uint64_t i = 0; i < L; ++i) {
-            if (i % (uint64_t) o_ratio == 0) memcpy(f->o + 4 * (i / (uint64_t) o_ratio), run, sizeof(run));
-            int code = dna_code(f->bwt[i]);
-            if (code >= 0) run[code]++;
+    {   // segments of SEG sample intervals: counts per segment first, then every segment fills its samples
+        const uint64_t R = (uint64_t) o_ratio, SEG = 1ull << 15, rows_per_seg = SEG * R, nseg = (L + rows_per_seg - 1) / rows_per_seg;
+        std::vector<uint64_t> segc((nseg + 1) * 4, 0);
+#pragma omp parallel for schedule(static)
+        for (uint64_t sg = 0; sg < nseg; ++sg) {
+            uint64_t c[4] = {0, 0, 0, 0};
+            const uint64_t lo = sg * rows_per_seg, hi = lo + rows_per_seg < L ? lo + rows_per_seg : L;
+            for (uint64_t i = lo; i < hi; ++i) { const int code = dna_code(f->bwt[i]); if (code >= 0) c[code]++; }
+            for (int x = 0; x < 4; ++x) segc[(sg + 1) * 4 + x] = c[x];
         }
+        for (uint64_t sg = 1; sg <= nseg; ++sg) for (int x = 0; x < 4; ++x) segc[sg * 4 + x] += segc[(sg - 1) * 4 + x];
+#pragma omp parallel for schedule(static)
+        for (uint64_t sg = 0; sg < nseg; ++sg) {
+            uint64_t run[4] = {segc[sg * 4], segc[sg * 4 + 1], segc[sg * 4 + 2], segc[sg * 4 + 3]};
+            const uint64_t lo = sg * rows_per_seg, hi = lo + rows_per_seg < L ? lo + rows_per_seg : L;
+            for (uint64_t i = lo; i < hi; ++i) {
+                if (i % R == 0) memcpy(f->o + 4 * (i / R), run, sizeof(run));
+                const int code = dna_code(f->bwt[i]);
+                if (code >= 0) run[code]++;
+            }
+        }
+        // (when L is a multiple of R the sample past the last row stays 0, as fmidx.c:135-147 leaves it)
     }
+    tm.lap("O table");
     // CSA (fmidx.c:153-163,194)
     f->csa_ratio = 4;
     f->csa_len = L / 4 + 1;
     f->csa = (uint64_t *) calloc(f->csa_len, sizeof(uint64_t));
+#pragma omp parallel for schedule(static)
     for (uint64_t i = 0; i < f->csa_len; ++i) f->csa[i] = i * 4 < L ? ui40v(sa[i * 4]) : 0;
 
+    tm.lap("csa");
     // lchash (lchash.c:52-73): the SA interval of every hlen-mer.  Suffixes sharing their first
     // hlen bases are contiguous in the SA, so one pass finds every interval's first/last row.
     // Quirk kept: fmi_aln starts from rows [1, L-1] (lchash.c:56), i.e. without the '$' row, so
@@ -264,18 +555,34 @@ extern "C" int lrm_host_index_build(const char *cat, uint64_t L, const lrm_mta_e
     auto code_at = [&](uint64_t row, uint64_t &code) -> bool {
         uint64_t pos = ui40v(sa[row]);
         if (pos + (uint64_t) hlen >= L - 1) return false;         // runs into '$', or is the "P$" row (see above)
+        if (pure) { code = pt.window(pos) >> (64 - 2 * hlen); return true; }   // first base most significant (lchash.c:36-49)
         uint64_t c = 0;
-        for (int i = 0; i < hlen; ++i) c = (c << 2) | (uint64_t) dna_code(cat[pos + i]);   // lchash.c:36-49 order
+        for (int i = 0; i < hlen; ++i) c = (c << 2) | (uint64_t) dna_code(cat[pos + i]);
         code = c;
         return true;
     };
-#pragma omp parallel for schedule(static)
-    for (uint64_t r = 0; r < L; ++r) {
-        uint64_t cur, other;
-        if (!code_at(r, cur)) continue;
-        if (r == 0 || !code_at(r - 1, other) || other != cur) out->lch.lc[2 * cur] = r;
-        if (r + 1 == L || !code_at(r + 1, other) || other != cur) out->lch.lc[2 * cur + 1] = r;
+    // one text access per row: the codes of a block of rows first, then the interval boundaries inside it
+    const uint64_t RB = 1ull << 16, nrb = (L + RB - 1) / RB;
+#pragma omp parallel
+    {
+        std::vector<uint64_t> codes(RB + 2);
+#pragma omp for schedule(dynamic, 4)
+        for (uint64_t b = 0; b < nrb; ++b) {
+            const uint64_t lo = b * RB, hi = lo + RB < L ? lo + RB : L;
+            const uint64_t NONE = ~0ull;
+            for (uint64_t r = (lo ? lo - 1 : lo); r < (hi < L ? hi + 1 : hi); ++r) {
+                uint64_t c;
+                codes[r + 1 - lo] = code_at(r, c) ? c : NONE;
+            }
+            for (uint64_t r = lo; r < hi; ++r) {
+                const uint64_t cur = codes[r + 1 - lo];
+                if (cur == NONE) continue;
+                if (r == 0 || codes[r - lo] != cur) out->lch.lc[2 * cur] = r;
+                if (r + 1 == L || codes[r + 2 - lo] != cur) out->lch.lc[2 * cur + 1] = r;
+            }
+        }
     }
+    tm.lap("lchash");
     return 0;
 }
 
@@ -378,8 +685,9 @@ extern "C" int64_t lrm_sa5_read(const char *p, lrm_ui40 *mem, uint64_t nitems) {
         size_t nb = fread(buf.data(), 1, want * 5, fp);
         uint64_t m = nb / 5;
         for (uint64_t j = 0; j < m; ++j) {
-            memcpy(&mem[got + j].low, &buf[j * 5], 4);
-            mem[got + j].high = buf[j * 5 + 4];
+            uint64_t v = 0;
+            memcpy(&v, &buf[j * 5], 5);                                      // little-endian: low, then high
+            memcpy(&mem[got + j], &v, 8);                                    // padding bytes zeroed
         }
         got += m;
         if (m < want) break;

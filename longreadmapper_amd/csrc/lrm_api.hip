@@ -9,6 +9,7 @@
 #include <new>
 #include <vector>
 #include <algorithm>
+#include <dlfcn.h>
 #include "lrm_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -35,7 +36,17 @@ extern "C" int lrm_device_count(void) {
 static inline uint64_t align256(uint64_t x) { return (x + 255ull) & ~255ull; }
 #define LRM_LCX_MAX 4096    // capacity of the long-interval side table
 
-static void blob_layout(uint64_t length, int hlen, int mta_len, LrmBlobHeader *h) {
+// LRM_SA_SAMPLED=r (r a power of two, 2..64): keep only SA rows i*r in the image -- the reference's `csa`
+// table (fmidx.c:153-163, csa_ratio 4) -- and locate the other rows with <= r-1 LF steps on the device
+// (csa_access, fmidx.c:315-331).  1 / unset: the full SA (sa_access, fmidx.c:18-33).
+static int env_sa_ratio() {
+    const char *e = getenv("LRM_SA_SAMPLED");
+    if (!e) return 1;
+    const int r = atoi(e);
+    return (r >= 2 && r <= 64 && (r & (r - 1)) == 0) ? r : 1;
+}
+
+static void blob_layout(uint64_t length, int hlen, int mta_len, int sa_ratio, LrmBlobHeader *h) {
     memset(h, 0, sizeof(*h));
     h->magic = LRM_BLOB_MAGIC;
     h->version = LRM_ABI_VERSION;
@@ -44,7 +55,8 @@ static void blob_layout(uint64_t length, int hlen, int mta_len, LrmBlobHeader *h
     h->mta_len = mta_len;
     h->n_blocks = (length + LRM_OCC_ROWS - 1) / LRM_OCC_ROWS + 1;   // +1: rank(loc) may touch the block of L-1 only; spare block keeps gathers in bounds
     h->lc_entries = 1ull << (2 * hlen);
-    h->sa_len = length;
+    h->sa_ratio = (uint64_t) sa_ratio;
+    h->sa_len = sa_ratio > 1 ? (length + sa_ratio - 1) / sa_ratio : length;
     h->con_len = length;
     uint64_t off = sizeof(LrmBlobHeader);
     h->off_occ = off;       off = align256(off + h->n_blocks * sizeof(LrmOccBlock));
@@ -58,7 +70,7 @@ static void blob_layout(uint64_t length, int hlen, int mta_len, LrmBlobHeader *h
 
 extern "C" uint64_t lrm_index_blob_bytes(uint64_t length, int hlen, int mta_len) {
     LrmBlobHeader h;
-    blob_layout(length, hlen, mta_len, &h);
+    blob_layout(length, hlen, mta_len, env_sa_ratio(), &h);
     return h.total_bytes;
 }
 
@@ -66,105 +78,268 @@ static inline int code_of(char c) {
     switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
 }
 
-extern "C" int lrm_index_pack_blob(const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
-                                   const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len,
-                                   void *blob, uint64_t blob_bytes) {
-    if (!fmi || !lch || !sa || !content || !blob) { lrm_set_error("null argument"); return -1; }
-    const uint64_t L = fmi->length;
-    if (L < 2 || L >= (1ull << 40)) { lrm_set_error("text length %llu outside [2, 2^40)", (unsigned long long) L); return -1; }
-    if (con_len != L) { lrm_set_error("content length %llu != fm length %llu", (unsigned long long) con_len, (unsigned long long) L); return -1; }
-    if (sa->len < L) { lrm_set_error("suffix array has %llu rows, need %llu", (unsigned long long) sa->len, (unsigned long long) L); return -1; }
-    if (lch->hlen < 1 || lch->hlen > 15) { lrm_set_error("hlen %d outside [1,15] (lchash.c:75-77)", lch->hlen); return -1; }
-    if (lch->len != 2ull << (2 * lch->hlen)) { lrm_set_error("lc table length %llu != 2*4^hlen", (unsigned long long) lch->len); return -1; }
-    if (mta_len < 0 || (mta_len > 0 && !mta)) { lrm_set_error("bad mta"); return -1; }
+// The image is produced SECTION BY SECTION in pieces of <= LRM_PACK_PIECE bytes, every piece by all host
+// threads, so that the same code fills a host blob (lrm_index_pack_blob) or a pair of pinned chunks whose DMA
+// overlaps the packing of the next piece (lrm_index_upload: no host copy of the image -- GRCh38 is a 63 GB
+// image next to 75 GB of reference-layout arrays).
+#define LRM_PACK_PIECE (64ull << 20)
+struct BlobPacker {
+    const lrm_dna_fmi *fmi; const lrm_lc_hash *lch; const lrm_sa_mem *sa; const char *content;
+    const lrm_mta_entry *mta; int mta_len;
     LrmBlobHeader h;
-    blob_layout(L, lch->hlen, mta_len, &h);
-    if (blob_bytes < h.total_bytes) { lrm_set_error("blob buffer too small"); return -1; }
-    h.c4[0] = fmi->c[(unsigned char) 'A']; h.c4[1] = fmi->c[(unsigned char) 'C'];
-    h.c4[2] = fmi->c[(unsigned char) 'G']; h.c4[3] = fmi->c[(unsigned char) 'T'];
-    uint8_t *base = (uint8_t *) blob;
-    memset(base, 0, sizeof(LrmBlobHeader));
+    uint64_t L;
+    static constexpr uint64_t SEG = 1ull << 20;          // rows per segment of the bwt prefix counts
+    std::vector<uint64_t> seg_cnt;                       // [seg][4]: # of A,C,G,T in bwt[0 .. seg*SEG)
+    uint64_t total[4];
+    std::vector<uint64_t> lcx;                           // side table, sorted {code, k, l}
 
-    // occ blocks from the bwt; cross-checked against the reference's sampled O table
-    LrmOccBlock *occ = (LrmOccBlock *) (base + h.off_occ);
-    memset(occ, 0, h.n_blocks * sizeof(LrmOccBlock));
-    uint64_t run[4] = {0, 0, 0, 0};
-    uint64_t dollar = ~0ull;
-    const uint64_t ratio = (uint64_t) fmi->o_ratio;
-    for (uint64_t i = 0; i < L; ++i) {
-        if ((i & (LRM_OCC_ROWS - 1)) == 0) {
-            LrmOccBlock *b = &occ[i >> 6];
-            for (int c = 0; c < 4; ++c) b->sym[c].cnt = run[c];
-        }
-        if (fmi->o && ratio > 0 && i % ratio == 0) {
-            const uint64_t *o = fmi->o + 4 * (i / ratio);
-            if (o[0] != run[0] || o[1] != run[1] || o[2] != run[2] || o[3] != run[3]) {
-                lrm_set_error("O table disagrees with bwt at row %llu", (unsigned long long) i);
-                return -1;
+    int init(const lrm_dna_fmi *fmi_, const lrm_lc_hash *lch_, const lrm_sa_mem *sa_, const char *content_,
+             uint64_t con_len, const lrm_mta_entry *mta_, int mta_len_) {
+        fmi = fmi_; lch = lch_; sa = sa_; content = content_; mta = mta_; mta_len = mta_len_;
+        if (!fmi || !lch || !sa || !content) { lrm_set_error("null argument"); return -1; }
+        L = fmi->length;
+        if (L < 2 || L >= (1ull << 40)) { lrm_set_error("text length %llu outside [2, 2^40)", (unsigned long long) L); return -1; }
+        if (con_len != L) { lrm_set_error("content length %llu != fm length %llu", (unsigned long long) con_len, (unsigned long long) L); return -1; }
+        if (sa->len < L) { lrm_set_error("suffix array has %llu rows, need %llu", (unsigned long long) sa->len, (unsigned long long) L); return -1; }
+        if (lch->hlen < 1 || lch->hlen > 15) { lrm_set_error("hlen %d outside [1,15] (lchash.c:75-77)", lch->hlen); return -1; }
+        if (lch->len != 2ull << (2 * lch->hlen)) { lrm_set_error("lc table length %llu != 2*4^hlen", (unsigned long long) lch->len); return -1; }
+        if (mta_len < 0 || (mta_len > 0 && !mta)) { lrm_set_error("bad mta"); return -1; }
+        blob_layout(L, lch->hlen, mta_len, env_sa_ratio(), &h);
+        h.c4[0] = fmi->c[(unsigned char) 'A']; h.c4[1] = fmi->c[(unsigned char) 'C'];
+        h.c4[2] = fmi->c[(unsigned char) 'G']; h.c4[3] = fmi->c[(unsigned char) 'T'];
+
+        // pass 1 over the bwt: per-segment symbol counts (parallel), the '$' row, alphabet check
+        const uint64_t nseg = (L + SEG - 1) / SEG;
+        seg_cnt.assign((nseg + 1) * 4, 0);
+        uint64_t dollar = ~0ull, n_dollar = 0, bad_row = ~0ull;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : n_dollar) reduction(min : dollar, bad_row)
+        for (uint64_t sg = 0; sg < nseg; ++sg) {
+            const uint64_t lo = sg * SEG, hi = lo + SEG < L ? lo + SEG : L;
+            uint64_t c[4] = {0, 0, 0, 0};
+            for (uint64_t i = lo; i < hi; ++i) {
+                const char ch = fmi->bwt[i];
+                const int code = code_of(ch);
+                if (code >= 0) c[code]++;
+                else if (ch == '$') { n_dollar++; if (i < dollar) dollar = i; }
+                else if (i < bad_row) bad_row = i;
             }
+            for (int x = 0; x < 4; ++x) seg_cnt[(sg + 1) * 4 + x] = c[x];
         }
-        char ch = fmi->bwt[i];
-        int code = code_of(ch);
-        if (code < 0) {
-            if (ch == '$' && dollar == ~0ull) { dollar = i; }
-            else { lrm_set_error("bwt row %llu holds byte 0x%02x (only upper-case ACGT and one '$' supported)", (unsigned long long) i, (unsigned) (unsigned char) ch); return -1; }
-        } else {
-            run[code]++;
-            occ[i >> 6].sym[code].mask |= 1ull << (i & 63);
+        if (bad_row != ~0ull || n_dollar > 1) {
+            const uint64_t r = bad_row != ~0ull ? bad_row : dollar;
+            lrm_set_error("bwt row %llu holds byte 0x%02x (only upper-case ACGT and one '$' supported)", (unsigned long long) r, (unsigned) (unsigned char) fmi->bwt[r]);
+            return -1;
         }
-    }
-    if (dollar == ~0ull) { lrm_set_error("bwt has no '$' row"); return -1; }
-    h.dollar_row = dollar;
-    for (uint64_t b = (L + LRM_OCC_ROWS - 1) / LRM_OCC_ROWS; b < h.n_blocks; ++b)     // spare block(s): final counts
-        for (int c = 0; c < 4; ++c) occ[b].sym[c].cnt = run[c];
+        if (n_dollar == 0) { lrm_set_error("bwt has no '$' row"); return -1; }
+        h.dollar_row = dollar;
+        for (uint64_t sg = 1; sg <= nseg; ++sg)
+            for (int x = 0; x < 4; ++x) seg_cnt[sg * 4 + x] += seg_cnt[(sg - 1) * 4 + x];
+        for (int x = 0; x < 4; ++x) total[x] = seg_cnt[nseg * 4 + x];
 
-    // lc table, permuted to the LSB-first code, 8 bytes per entry
-    uint64_t *lc = (uint64_t *) (base + h.off_lc);
-    const int hl = lch->hlen;
-    const uint64_t ne = h.lc_entries;
-    std::vector<uint64_t> over;
-    uint64_t long_thr = 0xFFFFFFull;           // testing knob: send shorter intervals through the side table too
-    if (const char *e = getenv("LRM_LCX_THRESHOLD")) { long_thr = strtoull(e, nullptr, 0); if (long_thr < 1 || long_thr > 0xFFFFFFull) long_thr = 0xFFFFFFull; }
+        // side table of the lc intervals that do not fit 24 bits of length
+        uint64_t long_thr = 0xFFFFFFull;           // testing knob: send shorter intervals through the side table too
+        if (const char *e = getenv("LRM_LCX_THRESHOLD")) { long_thr = strtoull(e, nullptr, 0); if (long_thr < 1 || long_thr > 0xFFFFFFull) long_thr = 0xFFFFFFull; }
+        lcx_thr = long_thr;
+        std::vector<uint64_t> over;
+        const uint64_t ne = h.lc_entries;
 #pragma omp parallel for schedule(static)
-    for (uint64_t num = 0; num < ne; ++num) {
-        uint64_t code = 0, t = num;
-        for (int i = 0; i < hl; ++i) { code = (code << 2) | (t & 3); t >>= 2; }   // reverse the 2-bit groups
-        const uint64_t k = lch->lc[2 * num], l = lch->lc[2 * num + 1];
-        uint64_t e = 0;
-        if (!(k == 0 && l == 0)) {
-            uint64_t cnt = l >= k ? l - k + 1 : 0;
+        for (uint64_t num = 0; num < ne; ++num) {
+            const uint64_t k = lch->lc[2 * num], l = lch->lc[2 * num + 1];
+            if (k == 0 && l == 0) continue;
+            const uint64_t cnt = l >= k ? l - k + 1 : 0;
             if (cnt == 0 || cnt >= long_thr || k >= (1ull << 40)) {
-                cnt = 0xFFFFFFull;
+                const uint64_t code = rev_groups(num, lch->hlen);
 #pragma omp critical
                 { over.push_back(code); over.push_back(k); over.push_back(l); }
             }
-            e = (k & ((1ull << 40) - 1ull)) | (cnt << 40);
         }
-        lc[code] = e;
-    }
-    if (over.size() / 3 > LRM_LCX_MAX) { lrm_set_error("too many long lchash intervals (%zu)", over.size() / 3); return -1; }
-    {
-        uint64_t *lcx = (uint64_t *) (base + h.off_lcx);
-        memset(lcx, 0xff, LRM_LCX_MAX * 24);
+        if (over.size() / 3 > LRM_LCX_MAX) { lrm_set_error("too many long lchash intervals (%zu)", over.size() / 3); return -1; }
         std::vector<size_t> ord(over.size() / 3);
         for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
         std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return over[3 * a] < over[3 * b]; });
+        lcx.assign(3 * (size_t) LRM_LCX_MAX, ~0ull);
         for (size_t i = 0; i < ord.size(); ++i)
             for (int f = 0; f < 3; ++f) lcx[3 * i + f] = over[3 * ord[i] + f];
         h.n_lcx = ord.size();
+        return 0;
     }
 
-    uint64_t *sav = (uint64_t *) (base + h.off_sa);
-#pragma omp parallel for schedule(static)
-    for (uint64_t i = 0; i < L; ++i)
-        sav[i] = ((uint64_t) sa->mem[i].high << 32) | (uint64_t) sa->mem[i].low;   // sa_use.h:27-29
+    uint64_t lcx_thr = 0xFFFFFFull;
+    static inline uint64_t rev_groups(uint64_t v, int hl) {          // reverse the order of the 2-bit groups
+        uint64_t code = 0;
+        for (int i = 0; i < hl; ++i) { code = (code << 2) | (v & 3); v >>= 2; }
+        return code;
+    }
 
-    memcpy(base + h.off_content, content, L);
-    base[h.off_content + L] = 0;
-    LrmMtaDev *md = (LrmMtaDev *) (base + h.off_mta);
-    for (int i = 0; i < mta_len; ++i) { md[i].offset = mta[i].offset; md[i].seq_len = (uint64_t) mta[i].seq_len; }
-    memcpy(base, &h, sizeof(h));
-    return 0;
+    // occ blocks [b0, b0 + nb): one {prefix count, occurrence mask} pair per symbol and 64 bwt rows;
+    // cross-checked against the reference's sampled O table (fmidx.c:128-150)
+    int fill_occ(uint64_t b0, uint64_t nb, LrmOccBlock *dst) const {
+        const uint64_t ratio = (uint64_t) fmi->o_ratio;
+        const uint64_t bps = SEG / LRM_OCC_ROWS;           // blocks per segment
+        uint64_t bad = ~0ull;
+        const uint64_t s0 = b0 / bps, s1 = (b0 + nb + bps - 1) / bps;
+#pragma omp parallel for schedule(dynamic, 1) reduction(min : bad)
+        for (uint64_t sg = s0; sg < s1; ++sg) {
+            uint64_t run[4];
+            const uint64_t nseg = (L + SEG - 1) / SEG;
+            const uint64_t sgc = sg < nseg ? sg : nseg;
+            for (int x = 0; x < 4; ++x) run[x] = seg_cnt[sgc * 4 + x];
+            const uint64_t blo = sg * bps > b0 ? sg * bps : b0, bhi = (sg + 1) * bps < b0 + nb ? (sg + 1) * bps : b0 + nb;
+            // rows of the segment before blo (a piece boundary inside a segment): count them
+            for (uint64_t i = sg * SEG; i < blo * LRM_OCC_ROWS && i < L; ++i) { const int c = code_of(fmi->bwt[i]); if (c >= 0) run[c]++; }
+            for (uint64_t b = blo; b < bhi; ++b) {
+                LrmOccBlock blk;
+                for (int x = 0; x < 4; ++x) { blk.sym[x].cnt = run[x]; blk.sym[x].mask = 0; }
+                const uint64_t r0 = b * LRM_OCC_ROWS, r1 = r0 + LRM_OCC_ROWS < L ? r0 + LRM_OCC_ROWS : L;
+                for (uint64_t i = r0; i < r1; ++i) {
+                    if (fmi->o && ratio > 0 && i % ratio == 0) {
+                        const uint64_t *o = fmi->o + 4 * (i / ratio);
+                        if ((o[0] != run[0] || o[1] != run[1] || o[2] != run[2] || o[3] != run[3]) && i < bad) bad = i;
+                    }
+                    const int c = code_of(fmi->bwt[i]);
+                    if (c >= 0) { run[c]++; blk.sym[c].mask |= 1ull << (i & 63); }
+                }
+                dst[b - b0] = blk;
+            }
+        }
+        if (bad != ~0ull) { lrm_set_error("O table disagrees with bwt at row %llu", (unsigned long long) bad); return -1; }
+        return 0;
+    }
+
+    // lc entries [c0, c0 + n) in device order (LSB-first code): gathered from the reference's table
+    void fill_lc(uint64_t c0, uint64_t n, uint64_t *dst) const {
+        const int hl = lch->hlen;
+#pragma omp parallel for schedule(static)
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint64_t num = rev_groups(c0 + i, hl);               // the permutation is an involution
+            const uint64_t k = lch->lc[2 * num], l = lch->lc[2 * num + 1];
+            uint64_t e = 0;
+            if (!(k == 0 && l == 0)) {
+                uint64_t cnt = l >= k ? l - k + 1 : 0;
+                if (cnt == 0 || cnt >= lcx_thr || k >= (1ull << 40)) cnt = 0xFFFFFFull;
+                e = (k & ((1ull << 40) - 1ull)) | (cnt << 40);
+            }
+            dst[i] = e;
+        }
+    }
+
+    // SA entries [e0, e0 + n) of the image: rows e*sa_ratio, as u64 (sa_use.h:27-29)
+    void fill_sa(uint64_t e0, uint64_t n, uint64_t *dst) const {
+        const uint64_t r = h.sa_ratio;
+#pragma omp parallel for schedule(static)
+        for (uint64_t i = 0; i < n; ++i) {
+            const lrm_ui40 &v = sa->mem[(e0 + i) * r];
+            dst[i] = ((uint64_t) v.high << 32) | (uint64_t) v.low;
+        }
+    }
+
+    // Emits the image in order as (offset, bytes) pieces through `sink`, which may consume the buffer
+    // asynchronously: next_buf() hands out the buffer for the next piece (>= LRM_PACK_PIECE bytes).
+    template <typename NextBuf, typename Sink>
+    int emit(NextBuf next_buf, Sink sink) const {
+        {   // header
+            uint8_t *b = next_buf();
+            if (!b) return -1;
+            memcpy(b, &h, sizeof(h));
+            if (sink(0, sizeof(h), b)) return -1;
+        }
+        const uint64_t bpp = LRM_PACK_PIECE / sizeof(LrmOccBlock);
+        for (uint64_t b0 = 0; b0 < h.n_blocks; b0 += bpp) {
+            const uint64_t nb = h.n_blocks - b0 < bpp ? h.n_blocks - b0 : bpp;
+            uint8_t *b = next_buf();
+            if (!b) return -1;
+            if (fill_occ(b0, nb, (LrmOccBlock *) b)) return -1;
+            if (sink(h.off_occ + b0 * sizeof(LrmOccBlock), nb * sizeof(LrmOccBlock), b)) return -1;
+        }
+        const uint64_t epp = LRM_PACK_PIECE / 8;
+        for (uint64_t c0 = 0; c0 < h.lc_entries; c0 += epp) {
+            const uint64_t n = h.lc_entries - c0 < epp ? h.lc_entries - c0 : epp;
+            uint8_t *b = next_buf();
+            if (!b) return -1;
+            fill_lc(c0, n, (uint64_t *) b);
+            if (sink(h.off_lc + c0 * 8, n * 8, b)) return -1;
+        }
+        {
+            uint8_t *b = next_buf();
+            if (!b) return -1;
+            memcpy(b, lcx.data(), (size_t) LRM_LCX_MAX * 24);
+            if (sink(h.off_lcx, (uint64_t) LRM_LCX_MAX * 24, b)) return -1;
+        }
+        for (uint64_t e0 = 0; e0 < h.sa_len; e0 += epp) {
+            const uint64_t n = h.sa_len - e0 < epp ? h.sa_len - e0 : epp;
+            uint8_t *b = next_buf();
+            if (!b) return -1;
+            fill_sa(e0, n, (uint64_t *) b);
+            if (sink(h.off_sa + e0 * 8, n * 8, b)) return -1;
+        }
+        for (uint64_t o = 0; o < L + 1; o += LRM_PACK_PIECE) {
+            const uint64_t n = L + 1 - o < LRM_PACK_PIECE ? L + 1 - o : LRM_PACK_PIECE;
+            uint8_t *b = next_buf();
+            if (!b) return -1;
+            const uint64_t nc = o + n > L ? L - o : n;                 // the byte after the text is a NUL
+            const uint64_t piece = 1ull << 20, np = (nc + piece - 1) / piece;
+#pragma omp parallel for schedule(static)
+            for (uint64_t i = 0; i < np; ++i) {
+                const uint64_t po = i * piece, pl = nc - po < piece ? nc - po : piece;
+                memcpy(b + po, content + o + po, pl);
+            }
+            if (nc < n) b[nc] = 0;
+            if (sink(h.off_content + o, n, b)) return -1;
+        }
+        {
+            uint8_t *b = next_buf();
+            if (!b) return -1;
+            LrmMtaDev *md = (LrmMtaDev *) b;
+            for (int i = 0; i < mta_len; ++i) { md[i].offset = mta[i].offset; md[i].seq_len = (uint64_t) mta[i].seq_len; }
+            const uint64_t bytes = (uint64_t) (mta_len > 0 ? mta_len : 1) * sizeof(LrmMtaDev);
+            if (mta_len == 0) memset(b, 0, bytes);
+            if (sink(h.off_mta, bytes, b)) return -1;
+        }
+        return 0;
+    }
+};
+
+extern "C" int lrm_index_pack_blob(const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
+                                   const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len,
+                                   void *blob, uint64_t blob_bytes) {
+    if (!blob) { lrm_set_error("null argument"); return -1; }
+    BlobPacker pk;
+    if (pk.init(fmi, lch, sa, content, con_len, mta, mta_len)) return -1;
+    if (mta_len > 0 && (uint64_t) mta_len * sizeof(LrmMtaDev) > LRM_PACK_PIECE) { lrm_set_error("too many sequences"); return -1; }
+    if (blob_bytes < pk.h.total_bytes) { lrm_set_error("blob buffer too small"); return -1; }
+    // pieces are written in place: the "next buffer" is the piece's own position in the blob, so the gaps between
+    // the 256-byte aligned sections are cleared first
+    uint8_t *base = (uint8_t *) blob;
+    // the emit order is fixed, so the destination of every piece is known in advance: replay the layout
+    struct Cursor { const BlobPacker *pk; uint64_t sec, pos; } cur = {&pk, 0, 0};
+    auto piece_offset = [&]() -> uint64_t {
+        const LrmBlobHeader &h = pk.h;
+        const uint64_t secs[7][3] = {{0, sizeof(LrmBlobHeader), sizeof(LrmBlobHeader)},
+                                      {h.off_occ, h.n_blocks * sizeof(LrmOccBlock), LRM_PACK_PIECE},
+                                      {h.off_lc, h.lc_entries * 8, LRM_PACK_PIECE},
+                                      {h.off_lcx, (uint64_t) LRM_LCX_MAX * 24, (uint64_t) LRM_LCX_MAX * 24},
+                                      {h.off_sa, h.sa_len * 8, LRM_PACK_PIECE},
+                                      {h.off_content, pk.L + 1, LRM_PACK_PIECE},
+                                      {h.off_mta, 1, 1}};
+        while (cur.sec < 7 && cur.pos >= secs[cur.sec][1]) { cur.sec++; cur.pos = 0; }
+        const uint64_t off = secs[cur.sec][0] + cur.pos;
+        cur.pos += secs[cur.sec][2];
+        return off;
+    };
+    {   // clear alignment gaps (and the spare tail) so that images of equal inputs are byte-identical
+        const LrmBlobHeader &h = pk.h;
+        const uint64_t ends[6][2] = {{h.off_occ + h.n_blocks * sizeof(LrmOccBlock), h.off_lc}, {h.off_lc + h.lc_entries * 8, h.off_lcx},
+                                      {h.off_lcx + (uint64_t) LRM_LCX_MAX * 24, h.off_sa}, {h.off_sa + h.sa_len * 8, h.off_content},
+                                      {h.off_content + pk.L + 1, h.off_mta},
+                                      {h.off_mta + (uint64_t) (mta_len > 0 ? mta_len : 1) * sizeof(LrmMtaDev), h.total_bytes}};
+        for (auto &e : ends) if (e[1] > e[0]) memset(base + e[0], 0, e[1] - e[0]);
+    }
+    return pk.emit([&]() -> uint8_t * { return base + piece_offset(); },
+                   [&](uint64_t off, uint64_t bytes, const uint8_t *buf) -> int {
+                       if (buf != base + off) { lrm_set_error("internal: piece order"); return -1; }
+                       (void) bytes;
+                       return 0;
+                   });
 }
 
 static int make_handle(lrm_index **out, void *d_blob, uint64_t bytes, int device, int owns, const LrmBlobHeader &h) {
@@ -172,6 +347,7 @@ static int make_handle(lrm_index **out, void *d_blob, uint64_t bytes, int device
     if (h.total_bytes > bytes) { lrm_set_error("index image truncated"); return -1; }
     lrm_index *ix = new (std::nothrow) lrm_index;
     if (!ix) { lrm_set_error("out of memory"); return -1; }
+    memset(ix, 0, sizeof(*ix));
     ix->d_blob = d_blob; ix->blob_bytes = bytes; ix->owns_blob = owns; ix->device = device; ix->hdr = h;
     uint8_t *b = (uint8_t *) d_blob;
     ix->view.occ = (const LrmOccBlock *) (b + h.off_occ);
@@ -185,14 +361,17 @@ static int make_handle(lrm_index **out, void *d_blob, uint64_t bytes, int device
     ix->view.sa_len = h.sa_len; ix->view.con_len = h.con_len;
     for (int i = 0; i < 4; ++i) ix->view.c4[i] = h.c4[i];
     ix->view.hlen = h.hlen; ix->view.mta_len = h.mta_len;
-    ix->view.lcl = nullptr; ix->view.hl = 0; ix->view.pad_ = 0; ix->d_lcl = nullptr;
+    ix->view.lcl = nullptr; ix->view.hl = 0;
+    ix->view.sa_shift = 0;
+    for (uint64_t r = h.sa_ratio > 1 ? h.sa_ratio : 1; r > 1; r >>= 1) ix->view.sa_shift++;
+    ix->n_peers = 1;
     if (lrm_bs_prepare_index(ix)) { delete ix; return -1; }
     if (lrm_lcl_prepare_index(ix)) { lrm_bs_free_index(ix); delete ix; return -1; }
     *out = ix;
     return 0;
 }
 
-static int require_device(int device) {
+int lrm_require_device(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -203,6 +382,7 @@ static int require_device(int device) {
     HIPCHK(hipSetDevice(device));
     return 0;
 }
+#define require_device lrm_require_device
 
 extern "C" int lrm_index_upload_blob(lrm_index **out, const void *blob, uint64_t blob_bytes, int device) {
     if (!out || !blob || blob_bytes < sizeof(LrmBlobHeader)) { lrm_set_error("bad blob"); return -1; }
@@ -224,152 +404,180 @@ extern "C" int lrm_index_adopt_device(lrm_index **out, void *d_blob, uint64_t bl
     return make_handle(out, d_blob, blob_bytes, device, 0, h);
 }
 
+// pack + upload without a host copy of the image: two pinned chunks, the DMA of one overlaps the packing of the other
 extern "C" int lrm_index_upload(lrm_index **out, const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
                                 const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len, int device) {
     if (!out || !fmi || !lch) { lrm_set_error("null argument"); return -1; }
     if (require_device(device)) return -1;
-    uint64_t bytes = lrm_index_blob_bytes(fmi->length, lch->hlen, mta_len);
-    void *blob = malloc(bytes);
-    if (!blob) { lrm_set_error("out of host memory for a %llu-byte index image", (unsigned long long) bytes); return -1; }
-    int rc = lrm_index_pack_blob(fmi, lch, sa, content, con_len, mta, mta_len, blob, bytes);
-    if (rc == 0) rc = lrm_index_upload_blob(out, blob, bytes, device);
-    free(blob);
-    return rc;
+    BlobPacker pk;
+    if (pk.init(fmi, lch, sa, content, con_len, mta, mta_len)) return -1;
+    if (mta_len > 0 && (uint64_t) mta_len * sizeof(LrmMtaDev) > LRM_PACK_PIECE) { lrm_set_error("too many sequences"); return -1; }
+    struct Res {
+        void *d = nullptr; void *pin[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; hipStream_t st = nullptr;
+        ~Res() {
+            if (st) { (void) hipStreamSynchronize(st); (void) hipStreamDestroy(st); }
+            for (int i = 0; i < 2; ++i) { if (pin[i]) (void) hipHostFree(pin[i]); if (ev[i]) (void) hipEventDestroy(ev[i]); }
+            if (d) (void) hipFree(d);
+        }
+    } r;
+    const uint64_t bytes = pk.h.total_bytes;
+    if (hipMalloc(&r.d, bytes) != hipSuccess) { lrm_set_error("hipMalloc of the %llu-byte index image failed", (unsigned long long) bytes); return -1; }
+    HIPCHK(hipMemset(r.d, 0, sizeof(LrmBlobHeader)));
+    HIPCHK(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipHostMalloc(&r.pin[i], LRM_PACK_PIECE, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming));
+    }
+    uint64_t seq = 0;
+    bool used[2] = {false, false};
+    int rc = pk.emit(
+        [&]() -> uint8_t * {
+            const int b = (int) (seq & 1);
+            if (used[b] && hipEventSynchronize(r.ev[b]) != hipSuccess) { lrm_set_error("index upload: event wait failed"); return nullptr; }
+            return (uint8_t *) r.pin[b];
+        },
+        [&](uint64_t off, uint64_t n, const uint8_t *buf) -> int {
+            const int b = (int) (seq & 1);
+            HIPCHK(hipMemcpyAsync((uint8_t *) r.d + off, buf, n, hipMemcpyHostToDevice, r.st));
+            HIPCHK(hipEventRecord(r.ev[b], r.st));
+            used[b] = true;
+            ++seq;
+            return 0;
+        });
+    if (rc) return -1;
+    HIPCHK(hipStreamSynchronize(r.st));
+    if (make_handle(out, r.d, bytes, device, 1, pk.h)) return -1;
+    r.d = nullptr;                 // owned by the handle now
+    return 0;
 }
 
-// Per-thread state of the host-buffer entry points: the workspace, device mirrors of the caller's arrays and two
-// pinned staging chunks.  The caller's buffers are pageable (alnmain.c mallocs them): a plain hipMemcpy stages
-// them through one driver thread at a fraction of the link rate, so the copies here run chunk-wise through
-// pinned memory, the host-side half of each chunk being an OpenMP memcpy that overlaps the DMA of the previous one.
-struct DevSlot {
-    void *p = nullptr; uint64_t cap = 0;
-    int ensure(uint64_t bytes) {
-        if (bytes <= cap) return 0;
-        if (p) (void) hipFree(p);
-        p = nullptr; cap = 0;
-        if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; return -1; }
-        cap = bytes;
-        return 0;
-    }
-    void release() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
-};
-#define LRM_STAGE_CHUNK (32ull << 20)
-struct DevSet { DevSlot reads, lens, best, store, nops, score, meta, mr; };
-struct HostCache {
-    lrm_workspace *ws;
-    DevSet set[2];                       // a batch goes through the device in sub-batches, alternating between the sets
-    void *pin_up[2], *pin_dn[2];         // pinned staging chunks per direction
-    hipStream_t up, down, comp;          // upload DMA, download DMA, kernels
-    hipEvent_t ev_pin_up[2], ev_pin_dn[2], ev_up[2], ev_done[2];
-    int pin_up_used[2];
-    uint64_t up_seq;
-    int staging_ready;
-};
-static thread_local HostCache g_cache = {};
 
-static int staging_init(HostCache &c) {
-    if (c.staging_ready) return 0;
-    for (int b = 0; b < 2; ++b) {
-        if (hipHostMalloc(&c.pin_up[b], LRM_STAGE_CHUNK, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc(&c.pin_dn[b], LRM_STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) { lrm_set_error("pinned staging allocation failed"); return -1; }
-        if (hipEventCreateWithFlags(&c.ev_pin_up[b], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c.ev_pin_dn[b], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c.ev_up[b], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c.ev_done[b], hipEventDisableTiming) != hipSuccess) { lrm_set_error("event creation failed"); return -1; }
-        c.pin_up_used[b] = 0;
+// ------------------------------------------------------------------------------------------
+// multi-GPU group: the image is packed and uploaded once (device devices[0]) and replicated to the other
+// devices over xGMI -- one RCCL broadcast when the devices are distinct and librccl is loadable, else
+// hipMemcpyPeer (or a plain device copy when a device is listed twice: a logical replica, used by tests on a
+// one-GPU box).  Every replica derives its own planar text / long seed table on its device.
+// ------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    typedef int (*init_all_t)(void **, int, const int *);
+    typedef int (*bcast_t)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    typedef int (*group_t)(void);
+    typedef int (*destroy_t)(void *);
+    typedef const char *(*errstr_t)(int);
+    void *lib = nullptr;
+    init_all_t init_all = nullptr; bcast_t bcast = nullptr; group_t gstart = nullptr, gend = nullptr; destroy_t destroy = nullptr;
+    errstr_t errstr = nullptr;
+    bool load() {
+        if (getenv("LRM_NO_RCCL")) return false;
+        for (const char *name : {"librccl.so.1", "librccl.so"}) { lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+        if (!lib) return false;
+        init_all = (init_all_t) dlsym(lib, "ncclCommInitAll"); bcast = (bcast_t) dlsym(lib, "ncclBroadcast");
+        gstart = (group_t) dlsym(lib, "ncclGroupStart"); gend = (group_t) dlsym(lib, "ncclGroupEnd");
+        destroy = (destroy_t) dlsym(lib, "ncclCommDestroy"); errstr = (errstr_t) dlsym(lib, "ncclGetErrorString");
+        return init_all && bcast && gstart && gend && destroy;
     }
-    if (hipStreamCreateWithFlags(&c.up, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c.down, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c.comp, hipStreamNonBlocking) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
-    c.up_seq = 0;
-    c.staging_ready = 1;
-    return 0;
-}
-static void staging_release(HostCache &c) {
-    if (c.staging_ready) {
-        (void) hipDeviceSynchronize();
-        for (int b = 0; b < 2; ++b) {
-            (void) hipHostFree(c.pin_up[b]); (void) hipHostFree(c.pin_dn[b]);
-            (void) hipEventDestroy(c.ev_pin_up[b]); (void) hipEventDestroy(c.ev_pin_dn[b]);
-            (void) hipEventDestroy(c.ev_up[b]); (void) hipEventDestroy(c.ev_done[b]);
+};
+
+// ncclBroadcast of the image from devs[0] into bufs[1..] (rccl.h:591; ncclUint8 = 1), in pieces of 256 MiB so
+// that RCCL pipelines across the xGMI links.  Returns 1 if RCCL is unavailable (caller falls back), -1 on error.
+int rccl_broadcast(const std::vector<int> &devs, const std::vector<void *> &bufs, uint64_t bytes) {
+    Rccl r;
+    if (!r.load()) return 1;
+    const int n = (int) devs.size();
+    std::vector<void *> comms((size_t) n, nullptr);
+    int rc = r.init_all(comms.data(), n, devs.data());
+    if (rc != 0) { lrm_set_error("ncclCommInitAll failed: %s", r.errstr ? r.errstr(rc) : "?"); return -1; }
+    std::vector<hipStream_t> st((size_t) n, nullptr);
+    int out = 0;
+    for (int i = 0; i < n && !out; ++i)
+        if (hipSetDevice(devs[i]) != hipSuccess || hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) out = -1;
+    const uint64_t piece = 256ull << 20;
+    for (uint64_t o = 0; o < bytes && !out; o += piece) {
+        const uint64_t l = bytes - o < piece ? bytes - o : piece;
+        r.gstart();
+        for (int i = 0; i < n; ++i) {
+            rc = r.bcast((const char *) bufs[i] + o, (char *) bufs[i] + o, (size_t) l, 1 /* ncclUint8 */, 0, comms[i], st[i]);
+            if (rc != 0) out = -1;
         }
-        (void) hipStreamDestroy(c.up); (void) hipStreamDestroy(c.down); (void) hipStreamDestroy(c.comp);
-        c.staging_ready = 0;
+        rc = r.gend();
+        if (rc != 0) out = -1;
     }
-    for (int b = 0; b < 2; ++b) {
-        DevSet &d = c.set[b];
-        d.reads.release(); d.lens.release(); d.best.release(); d.store.release();
-        d.nops.release(); d.score.release(); d.meta.release(); d.mr.release();
+    for (int i = 0; i < n; ++i) {
+        if (st[i]) { (void) hipSetDevice(devs[i]); if (hipStreamSynchronize(st[i]) != hipSuccess) out = -1; (void) hipStreamDestroy(st[i]); }
+        if (comms[i]) r.destroy(comms[i]);
     }
+    if (out) lrm_set_error("RCCL broadcast of the index image failed%s%s", rc ? ": " : "", rc && r.errstr ? r.errstr(rc) : "");
+    return out;
 }
-#define LRM_COPY_THREADS 8        // enough to outrun the link; a library must not fan out over every core of its host
-static void par_memcpy(void *dst, const void *src, uint64_t bytes) {
-    const uint64_t piece = 1ull << 20, np = (bytes + piece - 1) / piece;
-#pragma omp parallel for schedule(static) num_threads(LRM_COPY_THREADS)
-    for (uint64_t i = 0; i < np; ++i) {
-        const uint64_t o = i * piece, l = bytes - o < piece ? bytes - o : piece;
-        memcpy((char *) dst + o, (const char *) src + o, l);
-    }
-}
-// host -> device through the pinned chunks, enqueued on the upload stream; returns when the last chunk has been
-// handed to the DMA engine (not when it has landed: order later work behind the upload stream)
-static int stage_h2d(HostCache &c, void *d_dst, const void *h_src, uint64_t bytes) {
-    if (staging_init(c)) return -1;
-    for (uint64_t o = 0; o < bytes; o += LRM_STAGE_CHUNK, ++c.up_seq) {
-        const int b = (int) (c.up_seq & 1);
-        const uint64_t l = bytes - o < LRM_STAGE_CHUNK ? bytes - o : LRM_STAGE_CHUNK;
-        if (c.pin_up_used[b]) HIPCHK(hipEventSynchronize(c.ev_pin_up[b]));     // the chunk's previous DMA has drained
-        par_memcpy(c.pin_up[b], (const char *) h_src + o, l);
-        HIPCHK(hipMemcpyAsync((char *) d_dst + o, c.pin_up[b], l, hipMemcpyHostToDevice, c.up));
-        HIPCHK(hipEventRecord(c.ev_pin_up[b], c.up));
-        c.pin_up_used[b] = 1;
-    }
-    return 0;
-}
-// small host array -> device behind the staged upload (pageable source: the call returns once it is staged)
-static int small_h2d(HostCache &c, void *d_dst, const void *h_src, uint64_t bytes) {
-    HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c.up));
-    return 0;
-}
-// device -> host, `rows` rows of `width` bytes (device pitch spitch, host pitch dpitch); rows == 1 is a flat copy
-static int stage_d2h(HostCache &c, void *h_dst, uint64_t dpitch, const void *d_src, uint64_t spitch, uint64_t width,
-                     uint64_t rows) {
-    if (staging_init(c)) return -1;
-    if (width == 0 || rows == 0) return 0;
-    const bool flat = rows == 1;
-    const uint64_t unit = flat ? LRM_STAGE_CHUNK : (LRM_STAGE_CHUNK / width ? LRM_STAGE_CHUNK / width : 0);
-    if (unit == 0) { lrm_set_error("row wider than a staging chunk"); return -1; }
-    const uint64_t total = flat ? width : rows;                      // bytes (flat) or rows
-    uint64_t k = 0, o = 0, prev_o = 0, prev_l = 0;
-    while (true) {
-        const int b = (int) (k & 1);
-        const uint64_t l = o < total ? (total - o < unit ? total - o : unit) : 0;
-        if (l) {
-            if (flat) HIPCHK(hipMemcpyAsync(c.pin_dn[b], (const char *) d_src + o, l, hipMemcpyDeviceToHost, c.down));
-            else HIPCHK(hipMemcpy2DAsync(c.pin_dn[b], width, (const char *) d_src + o * spitch, spitch, width, l,
-                                         hipMemcpyDeviceToHost, c.down));
-            HIPCHK(hipEventRecord(c.ev_pin_dn[b], c.down));
+}  // namespace
+
+extern "C" int lrm_index_upload_multi(lrm_index **out, const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
+                                      const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len,
+                                      const int *devices, int ngpus) {
+    if (!out || ngpus < 1 || ngpus > 64) { lrm_set_error("bad argument (1 <= ngpus <= 64)"); return -1; }
+    std::vector<int> devs((size_t) ngpus);
+    for (int i = 0; i < ngpus; ++i) devs[i] = devices ? devices[i] : i;
+    lrm_index *root = nullptr;
+    if (lrm_index_upload(&root, fmi, lch, sa, content, con_len, mta, mta_len, devs[0])) return -1;
+    if (ngpus == 1) { *out = root; return 0; }
+    const uint64_t bytes = root->blob_bytes;
+    std::vector<void *> bufs((size_t) ngpus, nullptr);
+    bufs[0] = root->d_blob;
+    bool distinct = true;
+    for (int i = 0; i < ngpus; ++i) for (int k = 0; k < i; ++k) distinct &= devs[i] != devs[k];
+    auto cleanup = [&](int upto) { for (int i = 1; i < upto; ++i) if (bufs[i]) { (void) hipSetDevice(devs[i]); (void) hipFree(bufs[i]); } lrm_index_free(root); };
+    for (int i = 1; i < ngpus; ++i) {
+        if (lrm_require_device(devs[i]) || hipMalloc(&bufs[i], bytes) != hipSuccess) {
+            if (!bufs[i]) lrm_set_error("device %d: cannot allocate the %llu-byte index image", devs[i], (unsigned long long) bytes);
+            cleanup(i + 1);
+            return -1;
         }
-        if (prev_l) {                                                 // unpack the previous chunk while this one flies
-            const int pb = (int) ((k - 1) & 1);
-            HIPCHK(hipEventSynchronize(c.ev_pin_dn[pb]));
-            if (flat) par_memcpy((char *) h_dst + prev_o, c.pin_dn[pb], prev_l);
-            else {
-#pragma omp parallel for schedule(static) num_threads(LRM_COPY_THREADS)
-                for (uint64_t r = 0; r < prev_l; ++r)
-                    memcpy((char *) h_dst + (prev_o + r) * dpitch, (const char *) c.pin_dn[pb] + r * width, width);
-            }
-        }
-        if (l == 0) break;
-        prev_o = o; prev_l = l; o += l; ++k;
     }
+    int rc = distinct ? rccl_broadcast(devs, bufs, bytes) : 1;
+    if (rc == 1) {                                     // no RCCL (or logical replicas on one device): peer copies
+        rc = 0;
+        for (int i = 1; i < ngpus && !rc; ++i) {
+            (void) hipSetDevice(devs[i]);
+            const hipError_t e = devs[i] == devs[0] ? hipMemcpy(bufs[i], bufs[0], bytes, hipMemcpyDeviceToDevice)
+                                                     : hipMemcpyPeer(bufs[i], devs[i], bufs[0], devs[0], bytes);
+            if (e != hipSuccess) { lrm_set_error("replication of the index image to device %d failed: %s", devs[i], hipGetErrorString(e)); rc = -1; }
+        }
+    }
+    if (rc) { cleanup(ngpus); return -1; }
+    root->peers = new (std::nothrow) lrm_index *[(size_t) ngpus];
+    if (!root->peers) { cleanup(ngpus); lrm_set_error("out of memory"); return -1; }
+    root->peers[0] = root;
+    root->n_peers = 1;
+    for (int i = 1; i < ngpus; ++i) {
+        lrm_index *rep = nullptr;
+        if (lrm_require_device(devs[i]) || make_handle(&rep, bufs[i], bytes, devs[i], 1, root->hdr)) {
+            for (int k = i; k < ngpus; ++k) { (void) hipSetDevice(devs[k]); (void) hipFree(bufs[k]); }
+            lrm_index_free(root);                  // frees the replicas made so far
+            return -1;
+        }
+        root->peers[i] = rep;
+        root->n_peers = i + 1;
+    }
+    *out = root;
     return 0;
 }
+
+extern "C" int lrm_index_replicas(const lrm_index *idx) { return idx ? idx->n_peers : 0; }
+extern "C" lrm_index *lrm_index_replica(lrm_index *idx, int r) {
+    if (!idx || r < 0 || r >= idx->n_peers) return nullptr;
+    return idx->peers ? idx->peers[r] : idx;
+}
+
+// alnmain.c:554-557: the paired-end entry is declared and unimplemented in the reference ("todo"); it returns -1.
+extern "C" int lrm_pair_end(int argc, const char *argv[]) { (void) argc; (void) argv; return -1; }
 
 extern "C" void lrm_index_free(lrm_index *idx) {
     if (!idx) return;
+    for (int r = 1; r < idx->n_peers && idx->peers; ++r) lrm_index_free(idx->peers[r]);     // replicas of a multi-GPU group
+    delete[] idx->peers;
     (void) hipSetDevice(idx->device);
-    if (g_cache.ws && g_cache.ws->idx == idx) { lrm_workspace_free(g_cache.ws); g_cache.ws = nullptr; staging_release(g_cache); }
+    lrm_host_ctx_free(idx);                      // workspace, device mirrors, pinned staging, streams of the host-buffer calls
     lrm_bs_free_index(idx);
     if (idx->d_lcl) (void) hipFree(idx->d_lcl);
     if (idx->owns_blob && idx->d_blob) (void) hipFree(idx->d_blob);
@@ -386,6 +594,7 @@ extern "C" void lrm_workspace_free(lrm_workspace *ws) {
     (void) hipFree(ws->d_hcount); (void) hipFree(ws->d_counters);
     (void) hipFree(ws->d_qpl); (void) hipFree(ws->d_rflags);
     (void) hipFree(ws->d_ckpt); (void) hipFree(ws->d_codes); (void) hipFree(ws->d_ncodes);
+    if (ws->h_err) (void) hipHostFree((void *) ws->h_err);
     for (int i = 0; i < LRM_MAX_TIMED; ++i) {
         if (ws->ev_start[i]) (void) hipEventDestroy((hipEvent_t) ws->ev_start[i]);
         if (ws->ev_stop[i]) (void) hipEventDestroy((hipEvent_t) ws->ev_stop[i]);
@@ -436,8 +645,34 @@ extern "C" int lrm_workspace_create(lrm_workspace **out, lrm_index *idx, uint64_
         ws->bytes += a.bytes;
     }
     if (hipMemset(ws->d_counters, 0, sizeof(LrmDevCounters)) != hipSuccess) { lrm_workspace_free(ws); lrm_set_error("memset failed"); return -1; }
+    {   // error word: host-coherent pinned memory the kernels store to (never reset by a launch)
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+            if (h) (void) hipHostFree(h);
+            lrm_workspace_free(ws);
+            lrm_set_error("allocation of the workspace error word failed");
+            return -1;
+        }
+        memset(h, 0, 64);
+        ws->h_err = (volatile uint32_t *) h;
+        ws->d_err = (uint32_t *) d;
+    }
     *out = ws;
     return 0;
+}
+
+// Reads and clears the sticky error word.  Kernels that raised it have completed only if the caller has
+// synchronised with them; a later call sees the rest ("the next call after the faulty batch fails").
+int lrm_ws_take_error(lrm_workspace *ws) {
+    if (!ws || !ws->h_err) return 0;
+    const uint32_t e = *ws->h_err;
+    if (!e) return 0;
+    *ws->h_err = 0;
+    if (e & LRM_ERR_VOTE_OVERFLOW)
+        lrm_set_error("vote table overflow in the multi-pass tier: results of some phases of an earlier batch on this workspace are invalid");
+    else lrm_set_error("device error word 0x%x", e);
+    return -2;
 }
 
 static int check_ws(lrm_workspace *ws, lrm_index *idx, uint64_t n, uint32_t max_len, uint32_t seed_len, uint32_t thres) {
@@ -457,6 +692,7 @@ extern "C" int lrm_seed_batch_dev(lrm_index *idx, lrm_workspace *ws, const char 
     if (!idx || !d_reads || !d_lens || !d_best) { lrm_set_error("null argument"); return -1; }
     if (check_ws(ws, idx, n, max_len, p.seed_len, p.thres)) return -1;
     if (stride < max_len) { lrm_set_error("stride %llu < max_len %u", (unsigned long long) stride, max_len); return -1; }
+    if (lrm_ws_take_error(ws)) return -2;
     HIPCHK(hipSetDevice(idx->device));
     return lrm_launch_seed(idx, ws, d_reads, stride, d_lens, n, max_len, p.seed_len, p.thres, d_best, stream);
 }
@@ -470,6 +706,7 @@ extern "C" int lrm_extend_batch_dev(lrm_index *idx, lrm_workspace *ws, char *d_r
         return -1;
     }
     if (ws->idx != idx) { lrm_set_error("workspace does not belong to this index"); return -1; }
+    if (lrm_ws_take_error(ws)) return -2;
     HIPCHK(hipSetDevice(idx->device));
     return lrm_launch_extend(idx, ws, d_reads, stride, d_lens, n, max_len, d_best, gp, d_store, store_stride,
                              d_n_ops, d_score, d_meta, d_meta_r, stream);
@@ -491,8 +728,7 @@ extern "C" int lrm_workspace_stats(lrm_workspace *ws, lrm_stats *out, void *stre
     }
     out->reads_decided_phase0 = c.decided_phase0;
     out->gact_tiles = c.gact_tiles;
-    if (c.error_flags & 1ull) { lrm_set_error("vote table overflow in the multi-pass tier: results of some phases are invalid"); return -2; }
-    return 0;
+    return lrm_ws_take_error(ws);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -545,193 +781,6 @@ extern "C" const char *lrm_kernel_name(int k) {
     return k >= 0 && k < LRM_K_COUNT ? names[k] : "?";
 }
 
-// ------------------------------------------------------------------------------------------
-// host-buffer entry points (drop-in boundary): stage through device buffers
-// ------------------------------------------------------------------------------------------
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void) hipFree(p); }
-    int alloc(uint64_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? 0 : -1; }
-};
-
-static int get_cached_ws(lrm_index *idx, uint64_t n, uint32_t max_len, uint32_t seed_len, uint32_t thres, lrm_workspace **out) {
-    lrm_workspace *ws = g_cache.ws;
-    if (ws && ws->idx == idx && n <= ws->n_max && max_len <= ws->max_len && seed_len == ws->seed_len && thres <= ws->thres) {
-        *out = ws;
-        return 0;
-    }
-    if (ws) { lrm_workspace_free(ws); g_cache.ws = nullptr; }
-    if (lrm_workspace_create(&ws, idx, n, max_len, seed_len, thres)) return -1;
-    g_cache.ws = ws;
-    *out = ws;
-    return 0;
-}
-
-static uint32_t max_of(const uint32_t *lens, uint64_t n) {
-    uint32_t m = 0;
-    for (uint64_t i = 0; i < n; ++i) m = lens[i] > m ? lens[i] : m;
-    return m;
-}
-
-// Reads per device pass of the host-buffer entry points: the per-batch scratch is ~13 bytes per read base (seed
-// records 8, op bytes 2, codes, packed copies), so very large caller batches (the reference's sweeps use up to
-// 1 M reads, gen-sbatch-scripts.py:74) go through the device in slices of ~32 GB of scratch.  Results do not
-// depend on the slicing: there is no cross-read state.
-static uint64_t host_slice_reads(uint32_t max_len) {
-    if (const char *e = getenv("LRM_HOST_SLICE")) { const long long v = atoll(e); if (v >= 1) return (uint64_t) v; }   // test knob
-    const uint64_t per_read = 13ull * (max_len ? max_len : 1) + 4096;
-    uint64_t r = (32ull << 30) / per_read;
-    return r < 16384 ? 16384 : r;
-}
-
-// Sub-batches of one device pass: the upload of sub-batch k+1 (host memcpy into pinned chunks + DMA) and the
-// download of sub-batch k-1 run while the kernels of sub-batch k execute on their own stream.
-#define LRM_PIPE_MIN_READS 16384
-static uint64_t pipe_subs(uint64_t n) {
-    if (const char *e = getenv("LRM_HOST_SUBS")) { const long long v = atoll(e); if (v >= 1) return (uint64_t) v < n ? (uint64_t) v : n; }   // test knob
-    const uint64_t k = n / LRM_PIPE_MIN_READS;
-    return k < 2 ? 1 : (k > 4 ? 4 : k);
-}
-
-static int seed_slice(lrm_index *idx, const char *reads_buf, uint64_t stride, const uint32_t *lens, uint64_t n,
-                      uint32_t max_len, lrm_params p, lrm_entry *best_out) {
-    HostCache &hc = g_cache;
-    if (staging_init(hc)) return -1;
-    const uint64_t nsub = pipe_subs(n), sub = (n + nsub - 1) / nsub;
-    lrm_workspace *ws;
-    if (get_cached_ws(idx, sub, max_len, p.seed_len, p.thres, &ws)) return -1;
-    uint64_t prev_off = 0, prev_m = 0;
-    for (uint64_t k = 0, off = 0; off < n; ++k, off += sub) {
-        const int b = (int) (k & 1);
-        const uint64_t m = n - off < sub ? n - off : sub;
-        DevSet &d = hc.set[b];
-        if (d.reads.ensure(m * stride) || d.lens.ensure(m * 4) || d.best.ensure(m * sizeof(lrm_entry))) { lrm_set_error("device allocation failed"); return -1; }
-        if (stage_h2d(hc, d.reads.p, reads_buf + off * stride, m * stride)) return -1;
-        if (small_h2d(hc, d.lens.p, lens + off, m * 4)) return -1;
-        HIPCHK(hipEventRecord(hc.ev_up[b], hc.up));
-        HIPCHK(hipStreamWaitEvent(hc.comp, hc.ev_up[b], 0));
-        if (lrm_launch_seed(idx, ws, (const char *) d.reads.p, stride, (const uint32_t *) d.lens.p, m, max_len, p.seed_len,
-                            p.thres, (lrm_entry *) d.best.p, hc.comp)) return -1;
-        HIPCHK(hipEventRecord(hc.ev_done[b], hc.comp));
-        if (prev_m) {                                              // results of the previous sub-batch
-            const int pb = (int) ((k - 1) & 1);
-            HIPCHK(hipEventSynchronize(hc.ev_done[pb]));
-            HIPCHK(hipMemcpy(best_out + prev_off, hc.set[pb].best.p, prev_m * sizeof(lrm_entry), hipMemcpyDeviceToHost));
-        }
-        prev_off = off; prev_m = m;
-    }
-    {
-        const int pb = (int) (((n + sub - 1) / sub - 1) & 1);
-        HIPCHK(hipEventSynchronize(hc.ev_done[pb]));
-        HIPCHK(hipMemcpy(best_out + prev_off, hc.set[pb].best.p, prev_m * sizeof(lrm_entry), hipMemcpyDeviceToHost));
-    }
-    lrm_stats st;
-    if (lrm_workspace_stats(ws, &st, hc.comp)) return -1;
-    return 0;
-}
-
-extern "C" int lrm_seed_batch(lrm_index *idx, const char *reads_buf, uint64_t stride, const uint32_t *lens,
-                              uint64_t n, lrm_params p, lrm_entry *best_out) {
-    if (!idx || !reads_buf || !lens || !best_out) { lrm_set_error("null argument"); return -1; }
-    if (n == 0) return 0;
-    if (require_device(idx->device)) return -1;
-    const uint32_t max_len = max_of(lens, n);
-    if (stride < max_len) { lrm_set_error("stride < longest read"); return -1; }
-    const uint64_t slice = host_slice_reads(max_len);
-    for (uint64_t o = 0; o < n; o += slice) {
-        const uint64_t m = n - o < slice ? n - o : slice;
-        if (seed_slice(idx, reads_buf + o * stride, stride, lens + o, m, max_len, p, best_out + o)) return -1;
-    }
-    return 0;
-}
-
-static int extend_collect(HostCache &hc, int b, uint64_t m, char *reads_buf, uint64_t stride, lrm_cigar *cig_out,
-                          uint8_t *store_mem, uint64_t store_stride, uint64_t dstride, int *score_out,
-                          lrm_seq_meta *meta_out, int *meta_r_out) {
-    DevSet &d = hc.set[b];
-    HIPCHK(hipEventSynchronize(hc.ev_done[b]));
-    std::vector<int32_t> nops(m);
-    HIPCHK(hipMemcpy(nops.data(), d.nops.p, m * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(score_out, d.score.p, m * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(meta_out, d.meta.p, m * sizeof(lrm_seq_meta), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(meta_r_out, d.mr.p, m * 4, hipMemcpyDeviceToHost));
-    if (stage_d2h(hc, reads_buf, 0, d.reads.p, 0, m * stride, 1)) return -1;          // rev-comped reads travel back
-    int32_t mx = 0;                                                  // only the columns some read uses cross the link
-    for (uint64_t i = 0; i < m; ++i) mx = nops[i] > mx ? nops[i] : mx;
-    uint64_t width = ((uint64_t) mx + 63) & ~63ull;
-    if (width > store_stride) width = store_stride;
-    if (stage_d2h(hc, store_mem, store_stride, d.store.p, dstride, width, m)) return -1;
-    for (uint64_t i = 0; i < m; ++i) {                               // alnmain.c:322-325, mutils.c:99-104
-        cig_out[i].cigar = store_mem + i * store_stride;
-        cig_out[i].n_cigar_op = nops[i];
-        cig_out[i].score = score_out[i];
-    }
-    return 0;
-}
-
-static int extend_slice(lrm_index *idx, char *reads_buf, uint64_t stride, const uint32_t *lens, uint64_t n,
-                        uint32_t max_len, const lrm_entry *best, lrm_gact_params gp, lrm_cigar *cig_out,
-                        uint8_t *store_mem, uint64_t store_stride, int *score_out, lrm_seq_meta *meta_out,
-                        int *meta_r_out) {
-    HostCache &hc = g_cache;
-    if (staging_init(hc)) return -1;
-    const uint64_t nsub = pipe_subs(n), sub = (n + nsub - 1) / nsub;
-    lrm_workspace *ws = hc.ws;
-    if (!ws || ws->idx != idx) {
-        if (get_cached_ws(idx, sub, max_len, 20, 300, &ws)) return -1;   // extend only needs the counters block and the GACT scratch
-    } else if (sub > ws->n_max || max_len > ws->max_len) {
-        const uint32_t sl = ws->seed_len, th = ws->thres;
-        if (get_cached_ws(idx, sub, max_len, sl, th, &ws)) return -1;
-    }
-    const uint64_t dstride = (store_stride + 3) & ~3ull;     // the bit-sliced kernel stores CIGAR bytes four at a time
-    uint64_t prev_off = 0, prev_m = 0;
-    uint64_t k = 0;
-    for (uint64_t off = 0; off < n; ++k, off += sub) {
-        const int b = (int) (k & 1);
-        const uint64_t m = n - off < sub ? n - off : sub;
-        DevSet &d = hc.set[b];
-        if (d.reads.ensure(m * stride) || d.lens.ensure(m * 4) || d.best.ensure(m * sizeof(lrm_entry)) ||
-            d.store.ensure(m * dstride) || d.nops.ensure(m * 4) || d.score.ensure(m * 4) ||
-            d.meta.ensure(m * sizeof(lrm_seq_meta)) || d.mr.ensure(m * 4)) { lrm_set_error("device allocation failed"); return -1; }
-        if (stage_h2d(hc, d.reads.p, reads_buf + off * stride, m * stride)) return -1;
-        if (small_h2d(hc, d.lens.p, lens + off, m * 4)) return -1;
-        if (small_h2d(hc, d.best.p, best + off, m * sizeof(lrm_entry))) return -1;
-        HIPCHK(hipEventRecord(hc.ev_up[b], hc.up));
-        HIPCHK(hipStreamWaitEvent(hc.comp, hc.ev_up[b], 0));
-        if (lrm_launch_extend(idx, ws, (char *) d.reads.p, stride, (const uint32_t *) d.lens.p, m, max_len,
-                              (const lrm_entry *) d.best.p, gp, (uint8_t *) d.store.p, dstride, (int32_t *) d.nops.p,
-                              (int32_t *) d.score.p, (lrm_seq_meta *) d.meta.p, (int32_t *) d.mr.p, hc.comp)) return -1;
-        HIPCHK(hipEventRecord(hc.ev_done[b], hc.comp));
-        if (prev_m && extend_collect(hc, (int) ((k - 1) & 1), prev_m, reads_buf + prev_off * stride, stride,
-                                     cig_out + prev_off, store_mem + prev_off * store_stride, store_stride, dstride,
-                                     score_out + prev_off, meta_out + prev_off, meta_r_out + prev_off)) return -1;
-        prev_off = off; prev_m = m;
-    }
-    return extend_collect(hc, (int) ((k - 1) & 1), prev_m, reads_buf + prev_off * stride, stride, cig_out + prev_off,
-                          store_mem + prev_off * store_stride, store_stride, dstride, score_out + prev_off,
-                          meta_out + prev_off, meta_r_out + prev_off);
-}
-
-extern "C" int lrm_extend_batch(lrm_index *idx, char *reads_buf, uint64_t stride, const uint32_t *lens, uint64_t n,
-                                const lrm_entry *best, lrm_gact_params gp, lrm_cigar *cig_out, uint8_t *store_mem,
-                                uint64_t store_stride, int *score_out, lrm_seq_meta *meta_out, int *meta_r_out) {
-    if (!idx || !reads_buf || !lens || !best || !cig_out || !store_mem || !score_out || !meta_out || !meta_r_out) {
-        lrm_set_error("null argument");
-        return -1;
-    }
-    if (n == 0) return 0;
-    if (require_device(idx->device)) return -1;
-    const uint32_t max_len = max_of(lens, n);
-    if (stride < max_len) { lrm_set_error("stride < longest read"); return -1; }
-    const uint64_t slice = host_slice_reads(max_len);
-    for (uint64_t o = 0; o < n; o += slice) {
-        const uint64_t m = n - o < slice ? n - o : slice;
-        if (extend_slice(idx, reads_buf + o * stride, stride, lens + o, m, max_len, best + o, gp, cig_out + o,
-                         store_mem + o * store_stride, store_stride, score_out + o, meta_out + o, meta_r_out + o)) return -1;
-    }
-    return 0;
-}
-
 extern "C" void lrm_result_flags(const int *score, const int *meta_r, const lrm_seq_meta *meta, uint64_t n,
                                  int *flag_out, int *mapq_out, int *valid_out) {
     for (uint64_t i = 0; i < n; ++i) {                     // alnmain.c:460-474
@@ -745,6 +794,12 @@ extern "C" void lrm_result_flags(const int *score, const int *meta_r, const lrm_
 // ------------------------------------------------------------------------------------------
 // debug taps (tests only)
 // ------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void) hipFree(p); }
+    int alloc(uint64_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? 0 : -1; }
+};
+
 extern "C" int lrm_debug_seed_search(lrm_index *idx, const char *read, uint32_t len, uint32_t seed_len, uint32_t thres,
                                      int32_t *j_out, uint64_t *rr_out, uint64_t *k_out, uint64_t *l_out, uint64_t cap,
                                      uint64_t *n_out) {

@@ -1,0 +1,462 @@
+// lrm_host.hip -- the host-buffer entry points of liblrm_accel.so (the drop-in boundary):
+//   lrm_map_batch     PART 1 + PART 2 of single_end() for one batch in ONE device pass (alnmain.c:333-451)
+//   lrm_seed_batch    PART 1 alone (alnmain.c:333-405)
+//   lrm_extend_batch  PART 2 alone (alnmain.c:408-451)
+// on one device or on a multi-GPU group handle (lrm_index_upload_multi: reads partitioned by bases, one host
+// thread per replica, every replica writes its slice of the caller's arrays in place -- SURVEY 8(b)/(e); the
+// host loop this replaces is alnmain.c:302-330).
+//
+// A batch goes through a device in sub-batches over THREE sets of device mirrors: while the kernels of
+// sub-batch k run on the compute stream, the issuing thread uploads sub-batch k+1 and a second host thread
+// downloads the results of sub-batch k-1, so both directions of the link and the GPU are busy at once.
+// Caller buffers that are pinned (lrm_host_alloc / lrm_host_register) are handed to the DMA engines directly;
+// pageable ones (what alnmain.c mallocs) are staged chunk-wise through pinned memory, the host half of every
+// chunk being a multi-threaded memcpy that overlaps the DMA of the previous chunk.
+// No CPU fallback: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <condition_variable>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+#include "lrm_internal.h"
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    lrm_set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
+
+namespace {
+
+struct DevSlot {
+    void *p = nullptr; uint64_t cap = 0;
+    int ensure(uint64_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void) hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; return -1; }
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
+};
+constexpr uint64_t STAGE_CHUNK = 32ull << 20;
+constexpr int N_SETS = 3;
+constexpr int COPY_THREADS = 8;       // enough to outrun the link; a library must not fan out over every core of its host
+struct DevSet { DevSlot reads, lens, best, store, nops, score, meta, mr; };
+
+}  // namespace
+
+struct LrmHostCtx {
+    std::mutex mu;                       // one host-buffer call at a time per replica (re-entrant per handle otherwise)
+    lrm_workspace *ws = nullptr;
+    DevSet set[N_SETS];
+    void *pin_up[2] = {nullptr, nullptr}, *pin_dn[2] = {nullptr, nullptr};
+    hipStream_t up = nullptr, down = nullptr, comp = nullptr;
+    hipEvent_t ev_pin_up[2] = {nullptr, nullptr}, ev_pin_dn[2] = {nullptr, nullptr};
+    hipEvent_t ev_up[N_SETS] = {}, ev_done[N_SETS] = {};
+    bool pin_up_used[2] = {false, false};
+    uint64_t up_seq = 0;
+    bool ready = false;
+};
+
+namespace {
+
+int ctx_init(LrmHostCtx &c) {
+    if (c.ready) return 0;
+    for (int b = 0; b < 2; ++b) {
+        if (hipHostMalloc(&c.pin_up[b], STAGE_CHUNK, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&c.pin_dn[b], STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) { lrm_set_error("pinned staging allocation failed"); return -1; }
+        if (hipEventCreateWithFlags(&c.ev_pin_up[b], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c.ev_pin_dn[b], hipEventDisableTiming) != hipSuccess) { lrm_set_error("event creation failed"); return -1; }
+    }
+    for (int s = 0; s < N_SETS; ++s)
+        if (hipEventCreateWithFlags(&c.ev_up[s], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c.ev_done[s], hipEventDisableTiming) != hipSuccess) { lrm_set_error("event creation failed"); return -1; }
+    if (hipStreamCreateWithFlags(&c.up, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c.down, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c.comp, hipStreamNonBlocking) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
+    c.ready = true;
+    return 0;
+}
+
+void par_memcpy(void *dst, const void *src, uint64_t bytes) {
+    const uint64_t piece = 1ull << 20, np = (bytes + piece - 1) / piece;
+#pragma omp parallel for schedule(static) num_threads(COPY_THREADS)
+    for (uint64_t i = 0; i < np; ++i) {
+        const uint64_t o = i * piece, l = bytes - o < piece ? bytes - o : piece;
+        memcpy((char *) dst + o, (const char *) src + o, l);
+    }
+}
+
+// pinned (hipHostMalloc / hipHostRegister) memory can be handed to the DMA engines as it is
+bool is_pinned(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void) hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+// host -> device on the upload stream; returns when the last byte has been handed to the DMA engine (not when
+// it has landed: later work is ordered behind the upload stream)
+int h2d(LrmHostCtx &c, void *d_dst, const void *h_src, uint64_t bytes, bool pinned) {
+    if (bytes == 0) return 0;
+    if (pinned) { HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c.up)); return 0; }
+    for (uint64_t o = 0; o < bytes; o += STAGE_CHUNK, ++c.up_seq) {
+        const int b = (int) (c.up_seq & 1);
+        const uint64_t l = bytes - o < STAGE_CHUNK ? bytes - o : STAGE_CHUNK;
+        if (c.pin_up_used[b]) HIPCHK(hipEventSynchronize(c.ev_pin_up[b]));     // the chunk's previous DMA has drained
+        par_memcpy(c.pin_up[b], (const char *) h_src + o, l);
+        HIPCHK(hipMemcpyAsync((char *) d_dst + o, c.pin_up[b], l, hipMemcpyHostToDevice, c.up));
+        HIPCHK(hipEventRecord(c.ev_pin_up[b], c.up));
+        c.pin_up_used[b] = true;
+    }
+    return 0;
+}
+
+// device -> host on the download stream, `rows` rows of `width` bytes (device pitch spitch, host pitch dpitch);
+// rows == 1 is a flat copy.  Synchronous for the caller (the download thread).
+int d2h(LrmHostCtx &c, void *h_dst, uint64_t dpitch, const void *d_src, uint64_t spitch, uint64_t width, uint64_t rows,
+        bool pinned) {
+    if (width == 0 || rows == 0) return 0;
+    const bool flat = rows == 1;
+    if (pinned) {
+        if (flat) HIPCHK(hipMemcpyAsync(h_dst, d_src, width, hipMemcpyDeviceToHost, c.down));
+        else HIPCHK(hipMemcpy2DAsync(h_dst, dpitch, d_src, spitch, width, rows, hipMemcpyDeviceToHost, c.down));
+        HIPCHK(hipStreamSynchronize(c.down));
+        return 0;
+    }
+    const uint64_t unit = flat ? STAGE_CHUNK : STAGE_CHUNK / width;
+    if (unit == 0) { lrm_set_error("row wider than a staging chunk"); return -1; }
+    const uint64_t total = flat ? width : rows;                      // bytes (flat) or rows
+    uint64_t k = 0, o = 0, prev_o = 0, prev_l = 0;
+    while (true) {
+        const int b = (int) (k & 1);
+        const uint64_t l = o < total ? (total - o < unit ? total - o : unit) : 0;
+        if (l) {
+            if (flat) HIPCHK(hipMemcpyAsync(c.pin_dn[b], (const char *) d_src + o, l, hipMemcpyDeviceToHost, c.down));
+            else HIPCHK(hipMemcpy2DAsync(c.pin_dn[b], width, (const char *) d_src + o * spitch, spitch, width, l,
+                                         hipMemcpyDeviceToHost, c.down));
+            HIPCHK(hipEventRecord(c.ev_pin_dn[b], c.down));
+        }
+        if (prev_l) {                                                 // unpack the previous chunk while this one flies
+            const int pb = (int) ((k - 1) & 1);
+            HIPCHK(hipEventSynchronize(c.ev_pin_dn[pb]));
+            if (flat) par_memcpy((char *) h_dst + prev_o, c.pin_dn[pb], prev_l);
+            else {
+#pragma omp parallel for schedule(static) num_threads(COPY_THREADS)
+                for (uint64_t r = 0; r < prev_l; ++r)
+                    memcpy((char *) h_dst + (prev_o + r) * dpitch, (const char *) c.pin_dn[pb] + r * width, width);
+            }
+        }
+        if (l == 0) break;
+        prev_o = o; prev_l = l; o += l; ++k;
+    }
+    return 0;
+}
+
+uint32_t max_of(const uint32_t *lens, uint64_t n) {
+    uint32_t m = 0;
+    for (uint64_t i = 0; i < n; ++i) m = lens[i] > m ? lens[i] : m;
+    return m;
+}
+
+// Reads per device pass: the per-batch scratch is ~13 bytes per read base (seed records, op bytes, codes, packed
+// copies), so very large caller batches (the reference's sweeps use up to 1 M reads, gen-sbatch-scripts.py:74) go
+// through the device in slices of ~32 GB of scratch.  Results do not depend on the slicing: there is no
+// cross-read state.
+uint64_t host_slice_reads(uint32_t max_len) {
+    if (const char *e = getenv("LRM_HOST_SLICE")) { const long long v = atoll(e); if (v >= 1) return (uint64_t) v; }   // test knob
+    const uint64_t per_read = 13ull * (max_len ? max_len : 1) + 4096;
+    uint64_t r = (32ull << 30) / per_read;
+    return r < 16384 ? 16384 : r;
+}
+
+// Sub-batches of one device pass (see the header comment); at least LRM_PIPE_MIN_READS reads each, because the
+// bit-sliced extension needs that many to fill the chip.
+constexpr uint64_t PIPE_MIN_READS = 16384;
+uint64_t pipe_subs(uint64_t n) {
+    if (const char *e = getenv("LRM_HOST_SUBS")) { const long long v = atoll(e); if (v >= 1) return (uint64_t) v < n ? (uint64_t) v : n; }   // test knob
+    const uint64_t k = n / PIPE_MIN_READS;
+    return k < 2 ? 1 : (k > 6 ? 6 : k);
+}
+
+enum { DO_SEED = 1, DO_EXTEND = 2 };
+struct MapJob {
+    int mode;
+    char *reads; uint64_t stride; const uint32_t *lens; uint64_t n;
+    lrm_params p; lrm_gact_params gp;
+    const lrm_entry *best_in; lrm_entry *best_out;
+    lrm_cigar *cig; uint8_t *store_mem; uint64_t store_stride; int *score; lrm_seq_meta *meta; int *meta_r;
+    MapJob slice(uint64_t o, uint64_t m) const {
+        MapJob j = *this;
+        j.reads = reads + o * stride; j.lens = lens + o; j.n = m;
+        if (best_in) j.best_in = best_in + o;
+        if (best_out) j.best_out = best_out + o;
+        if (cig) { j.cig = cig + o; j.store_mem = store_mem + o * store_stride; j.score = score + o; j.meta = meta + o; j.meta_r = meta_r + o; }
+        return j;
+    }
+};
+
+int get_ws(LrmHostCtx &c, lrm_index *idx, uint64_t n, uint32_t max_len, uint32_t seed_len, uint32_t thres, bool exact) {
+    lrm_workspace *ws = c.ws;
+    if (ws && n <= ws->n_max && max_len <= ws->max_len && (!exact || (seed_len == ws->seed_len && thres <= ws->thres))) return 0;
+    if (ws && !exact) { seed_len = ws->seed_len; thres = ws->thres; }     // extend only: keep the seed shape of the cached one
+    if (ws) { lrm_workspace_free(ws); c.ws = nullptr; }
+    if (lrm_workspace_create(&ws, idx, n, max_len, seed_len, thres)) return -1;
+    c.ws = ws;
+    return 0;
+}
+
+// hand-off between the issuing thread and the download thread
+struct Pipe {
+    std::mutex m;
+    std::condition_variable cv;
+    uint64_t issued = 0, collected = 0;
+    bool stop = false;
+    int rc = 0;
+    char err[512] = "";
+    void fail(int code) {
+        std::lock_guard<std::mutex> g(m);
+        if (!rc) { rc = code; snprintf(err, sizeof(err), "%s", lrm_last_error()); }
+        cv.notify_all();
+    }
+};
+
+struct SubBatch { uint64_t off, m; };
+
+// download of sub-batch k (runs on the download thread once ev_done[k % N_SETS] has fired)
+int collect(LrmHostCtx &c, const MapJob &j, const SubBatch &sb, int s, uint64_t dstride, bool pin_reads, bool pin_store) {
+    DevSet &d = c.set[s];
+    HIPCHK(hipEventSynchronize(c.ev_done[s]));
+    if (lrm_ws_take_error(c.ws)) return -2;                        // raised by this or an earlier sub-batch: never lost
+    const uint64_t m = sb.m, o = sb.off;
+    if (j.mode & DO_SEED) HIPCHK(hipMemcpyAsync(j.best_out + o, d.best.p, m * sizeof(lrm_entry), hipMemcpyDeviceToHost, c.down));
+    if (!(j.mode & DO_EXTEND)) { HIPCHK(hipStreamSynchronize(c.down)); return 0; }
+    std::vector<int32_t> nops(m);
+    HIPCHK(hipMemcpyAsync(nops.data(), d.nops.p, m * 4, hipMemcpyDeviceToHost, c.down));
+    HIPCHK(hipMemcpyAsync(j.score + o, d.score.p, m * 4, hipMemcpyDeviceToHost, c.down));
+    HIPCHK(hipMemcpyAsync(j.meta + o, d.meta.p, m * sizeof(lrm_seq_meta), hipMemcpyDeviceToHost, c.down));
+    HIPCHK(hipMemcpyAsync(j.meta_r + o, d.mr.p, m * 4, hipMemcpyDeviceToHost, c.down));
+    HIPCHK(hipStreamSynchronize(c.down));
+    if (d2h(c, j.reads + o * j.stride, 0, d.reads.p, 0, m * j.stride, 1, pin_reads)) return -1;     // rev-comped reads travel back (alnmain.c:437)
+    int32_t mx = 0;                                                  // only the columns some read uses cross the link
+    for (uint64_t i = 0; i < m; ++i) mx = nops[i] > mx ? nops[i] : mx;
+    uint64_t width = ((uint64_t) mx + 63) & ~63ull;
+    if (width > j.store_stride) width = j.store_stride;
+    if (d2h(c, j.store_mem + o * j.store_stride, j.store_stride, d.store.p, dstride, width, m, pin_store)) return -1;
+    for (uint64_t i = 0; i < m; ++i) {                               // alnmain.c:322-325, mutils.c:99-104
+        j.cig[o + i].cigar = j.store_mem + (o + i) * j.store_stride;
+        j.cig[o + i].n_cigar_op = nops[i];
+        j.cig[o + i].score = j.score[o + i];
+    }
+    return 0;
+}
+
+// one device pass over a slice of the job: the three-stage pipeline
+int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) {
+    const uint64_t n = j.n, nsub = pipe_subs(n), sub = (n + nsub - 1) / nsub;
+    if (get_ws(c, idx, sub, max_len, j.p.seed_len, j.p.thres, (j.mode & DO_SEED) != 0)) return -1;
+    lrm_workspace *ws = c.ws;
+    const uint64_t dstride = (j.store_stride + 3) & ~3ull;           // the bit-sliced kernel stores CIGAR bytes four at a time
+    const bool pin_reads = is_pinned(j.reads), pin_store = (j.mode & DO_EXTEND) && is_pinned(j.store_mem);
+    std::vector<SubBatch> subs;
+    for (uint64_t off = 0; off < n; off += sub) subs.push_back({off, n - off < sub ? n - off : sub});
+
+    Pipe pipe;
+    const int device = idx->device;
+    std::thread downloader([&]() {
+        if (hipSetDevice(device) != hipSuccess) { lrm_set_error("hipSetDevice failed on the download thread"); pipe.fail(-1); return; }
+        for (uint64_t k = 0; k < subs.size(); ++k) {
+            {
+                std::unique_lock<std::mutex> g(pipe.m);
+                pipe.cv.wait(g, [&] { return pipe.issued > k || pipe.stop || pipe.rc; });
+                if (pipe.rc || pipe.issued <= k) return;
+            }
+            const int rc = collect(c, j, subs[k], (int) (k % N_SETS), dstride, pin_reads, pin_store);
+            if (rc) { pipe.fail(rc); return; }
+            { std::lock_guard<std::mutex> g(pipe.m); pipe.collected = k + 1; }
+            pipe.cv.notify_all();
+        }
+    });
+
+    int rc = 0;
+    for (uint64_t k = 0; k < subs.size() && !rc; ++k) {
+        const int s = (int) (k % N_SETS);
+        const uint64_t m = subs[k].m, off = subs[k].off;
+        {   // the set's previous occupant (sub-batch k - N_SETS) has been downloaded
+            std::unique_lock<std::mutex> g(pipe.m);
+            pipe.cv.wait(g, [&] { return pipe.collected + N_SETS > k || pipe.rc; });
+            if (pipe.rc) break;
+        }
+        DevSet &d = c.set[s];
+        auto issue = [&]() -> int {
+            if (d.reads.ensure(m * j.stride) || d.lens.ensure(m * 4) || d.best.ensure(m * sizeof(lrm_entry))) { lrm_set_error("device allocation failed"); return -1; }
+            if ((j.mode & DO_EXTEND) && (d.store.ensure(m * dstride) || d.nops.ensure(m * 4) || d.score.ensure(m * 4) ||
+                                          d.meta.ensure(m * sizeof(lrm_seq_meta)) || d.mr.ensure(m * 4))) { lrm_set_error("device allocation failed"); return -1; }
+            if (h2d(c, d.reads.p, j.reads + off * j.stride, m * j.stride, pin_reads)) return -1;
+            HIPCHK(hipMemcpyAsync(d.lens.p, j.lens + off, m * 4, hipMemcpyHostToDevice, c.up));
+            if (!(j.mode & DO_SEED)) HIPCHK(hipMemcpyAsync(d.best.p, j.best_in + off, m * sizeof(lrm_entry), hipMemcpyHostToDevice, c.up));
+            HIPCHK(hipEventRecord(c.ev_up[s], c.up));
+            HIPCHK(hipStreamWaitEvent(c.comp, c.ev_up[s], 0));
+            if ((j.mode & DO_SEED) && lrm_launch_seed(idx, ws, (const char *) d.reads.p, j.stride, (const uint32_t *) d.lens.p, m, max_len,
+                                                      j.p.seed_len, j.p.thres, (lrm_entry *) d.best.p, c.comp)) return -1;
+            if ((j.mode & DO_EXTEND) && lrm_launch_extend(idx, ws, (char *) d.reads.p, j.stride, (const uint32_t *) d.lens.p, m, max_len,
+                                                          (const lrm_entry *) d.best.p, j.gp, (uint8_t *) d.store.p, dstride,
+                                                          (int32_t *) d.nops.p, (int32_t *) d.score.p, (lrm_seq_meta *) d.meta.p,
+                                                          (int32_t *) d.mr.p, c.comp)) return -1;
+            HIPCHK(hipEventRecord(c.ev_done[s], c.comp));
+            return 0;
+        };
+        rc = issue();
+        if (rc) { pipe.fail(rc); break; }
+        { std::lock_guard<std::mutex> g(pipe.m); pipe.issued = k + 1; }
+        pipe.cv.notify_all();
+    }
+    { std::lock_guard<std::mutex> g(pipe.m); pipe.stop = true; }
+    pipe.cv.notify_all();
+    downloader.join();
+    if (pipe.rc) {
+        (void) hipStreamSynchronize(c.comp); (void) hipStreamSynchronize(c.up); (void) hipStreamSynchronize(c.down);
+        lrm_set_error("%s", pipe.err);
+        return pipe.rc;
+    }
+    return 0;
+}
+
+int run_replica(lrm_index *idx, const MapJob &j) {
+    if (lrm_require_device(idx->device)) return -1;
+    if (!idx->host) {
+        idx->host = new (std::nothrow) LrmHostCtx;
+        if (!idx->host) { lrm_set_error("out of memory"); return -1; }
+    }
+    LrmHostCtx &c = *idx->host;
+    std::lock_guard<std::mutex> g(c.mu);
+    if (ctx_init(c)) return -1;
+    const uint32_t max_len = max_of(j.lens, j.n);
+    if (j.stride < max_len) { lrm_set_error("stride < longest read"); return -1; }
+    if ((j.mode & DO_EXTEND) && j.store_stride < 2ull * max_len) { lrm_set_error("store_stride < 2 * longest read (alnmain.c:316-320)"); return -1; }
+    const uint64_t slice = host_slice_reads(max_len);
+    for (uint64_t o = 0; o < j.n; o += slice) {
+        const MapJob s = j.slice(o, j.n - o < slice ? j.n - o : slice);
+        const int rc = run_slice(idx, c, s, max_len);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// contiguous slices balanced by cumulative bases, not by read count (100 kbp reads next to 1 kbp ones)
+void partition_by_bases(const uint32_t *lens, uint64_t n, int parts, std::vector<uint64_t> &cuts) {
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; ++i) total += lens[i];
+    cuts.assign((size_t) parts + 1, n);
+    cuts[0] = 0;
+    uint64_t acc = 0, i = 0;
+    for (int r = 1; r < parts; ++r) {
+        const uint64_t target = (uint64_t) ((__uint128_t) total * (uint64_t) r / (uint64_t) parts);
+        while (i < n && acc < target) acc += lens[i++];
+        cuts[r] = i;
+    }
+}
+
+int run_job(lrm_index *idx, const MapJob &j) {
+    if (j.n == 0) return 0;
+    if (idx->n_peers <= 1 || !idx->peers) return run_replica(idx, j);
+    const int np = idx->n_peers;
+    std::vector<uint64_t> cuts;
+    partition_by_bases(j.lens, j.n, np, cuts);
+    std::vector<int> rcs((size_t) np, 0);
+    std::vector<std::string> errs((size_t) np);
+    std::vector<std::thread> th;
+    for (int r = 0; r < np; ++r) {
+        th.emplace_back([&, r]() {                                   // one host thread per replica / device
+            const uint64_t lo = cuts[r], hi = cuts[r + 1];
+            if (hi <= lo) return;
+            rcs[r] = run_replica(idx->peers[r], j.slice(lo, hi - lo));
+            if (rcs[r]) errs[r] = lrm_last_error();
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int r = 0; r < np; ++r)
+        if (rcs[r]) { lrm_set_error("replica %d (device %d): %s", r, idx->peers[r]->device, errs[r].c_str()); return rcs[r]; }
+    return 0;
+}
+
+}  // namespace
+
+void lrm_host_ctx_free(lrm_index *idx) {
+    LrmHostCtx *c = idx->host;
+    if (!c) return;
+    idx->host = nullptr;
+    if (c->ready) {
+        (void) hipStreamSynchronize(c->comp); (void) hipStreamSynchronize(c->up); (void) hipStreamSynchronize(c->down);
+        for (int b = 0; b < 2; ++b) {
+            (void) hipHostFree(c->pin_up[b]); (void) hipHostFree(c->pin_dn[b]);
+            (void) hipEventDestroy(c->ev_pin_up[b]); (void) hipEventDestroy(c->ev_pin_dn[b]);
+        }
+        for (int s = 0; s < N_SETS; ++s) { (void) hipEventDestroy(c->ev_up[s]); (void) hipEventDestroy(c->ev_done[s]); }
+        (void) hipStreamDestroy(c->up); (void) hipStreamDestroy(c->down); (void) hipStreamDestroy(c->comp);
+    }
+    if (c->ws) lrm_workspace_free(c->ws);
+    for (auto &d : c->set) {
+        d.reads.release(); d.lens.release(); d.best.release(); d.store.release();
+        d.nops.release(); d.score.release(); d.meta.release(); d.mr.release();
+    }
+    delete c;
+}
+
+extern "C" int lrm_seed_batch(lrm_index *idx, const char *reads_buf, uint64_t stride, const uint32_t *lens,
+                              uint64_t n, lrm_params p, lrm_entry *best_out) {
+    if (!idx || !reads_buf || !lens || !best_out) { lrm_set_error("null argument"); return -1; }
+    MapJob j = {};
+    j.mode = DO_SEED; j.reads = const_cast<char *>(reads_buf); j.stride = stride; j.lens = lens; j.n = n; j.p = p; j.best_out = best_out;
+    return run_job(idx, j);
+}
+
+extern "C" int lrm_extend_batch(lrm_index *idx, char *reads_buf, uint64_t stride, const uint32_t *lens, uint64_t n,
+                                const lrm_entry *best, lrm_gact_params gp, lrm_cigar *cig_out, uint8_t *store_mem,
+                                uint64_t store_stride, int *score_out, lrm_seq_meta *meta_out, int *meta_r_out) {
+    if (!idx || !reads_buf || !lens || !best || !cig_out || !store_mem || !score_out || !meta_out || !meta_r_out) {
+        lrm_set_error("null argument");
+        return -1;
+    }
+    MapJob j = {};
+    j.mode = DO_EXTEND; j.reads = reads_buf; j.stride = stride; j.lens = lens; j.n = n; j.gp = gp; j.best_in = best;
+    j.p.seed_len = 20; j.p.thres = 300;                              // only sizes the workspace when none is cached yet
+    j.cig = cig_out; j.store_mem = store_mem; j.store_stride = store_stride; j.score = score_out; j.meta = meta_out; j.meta_r = meta_r_out;
+    return run_job(idx, j);
+}
+
+extern "C" int lrm_map_batch(lrm_index *idx, char *reads_buf, uint64_t stride, const uint32_t *lens, uint64_t n,
+                             lrm_params p, lrm_gact_params gp, lrm_entry *best_out, lrm_cigar *cig_out, uint8_t *store_mem,
+                             uint64_t store_stride, int *score_out, lrm_seq_meta *meta_out, int *meta_r_out) {
+    if (!idx || !reads_buf || !lens || !best_out || !cig_out || !store_mem || !score_out || !meta_out || !meta_r_out) {
+        lrm_set_error("null argument");
+        return -1;
+    }
+    MapJob j = {};
+    j.mode = DO_SEED | DO_EXTEND; j.reads = reads_buf; j.stride = stride; j.lens = lens; j.n = n; j.p = p; j.gp = gp;
+    j.best_out = best_out;
+    j.cig = cig_out; j.store_mem = store_mem; j.store_stride = store_stride; j.score = score_out; j.meta = meta_out; j.meta_r = meta_r_out;
+    return run_job(idx, j);
+}
+
+// Pinned host memory for the caller's batch buffers (reads_buf, store_mem): the DMA engines read and write it
+// directly, no staging copy.  lrm_host_register pins memory the caller already owns (malloc'd at alnmain.c:297-320).
+extern "C" void *lrm_host_alloc(uint64_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void) hipGetLastError(); lrm_set_error("hipHostMalloc of %llu bytes failed", (unsigned long long) bytes); return nullptr; }
+    return p;
+}
+extern "C" void lrm_host_free(void *p) { if (p) (void) hipHostFree(p); }
+extern "C" int lrm_host_register(void *p, uint64_t bytes) {
+    if (!p || !bytes) { lrm_set_error("bad argument"); return -1; }
+    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterPortable));
+    return 0;
+}
+extern "C" int lrm_host_unregister(void *p) {
+    if (!p) return 0;
+    HIPCHK(hipHostUnregister(p));
+    return 0;
+}

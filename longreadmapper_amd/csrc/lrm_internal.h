@@ -18,7 +18,8 @@
 //                  stays resident in the 256 MiB Infinity Cache.  Intervals of >= 2^24-1 rows are
 //                  marked 0xFFFFFF and resolved through a small sorted side table [lcx].
 //                  (reference order: first base most significant, lchash.c:36-49; the packer permutes.)
-//   [sa]           u64 per row (values of sa_access, fmidx.c:18-33)
+//   [sa]           u64 per row (values of sa_access, fmidx.c:18-33); with LRM_SA_SAMPLED=r only rows i*r
+//                  (csa, fmidx.c:153-163) and the kernels locate the others by LF steps (csa_access, fmidx.c:315-331)
 //   [content]      the .cat text, 1 byte per base (GACT target side)
 //   [mta]          {u64 offset, u64 seq_len} per sequence (accaln.h:67-71 without names)
 //
@@ -53,7 +54,8 @@ struct LrmBlobHeader {
     uint64_t total_bytes;
     int32_t hlen, mta_len;
     uint64_t off_lcx, n_lcx;   // side table of {code, k, l} for intervals too long for 24 bits
-    uint64_t reserved[11];
+    uint64_t sa_ratio;         // 0/1: [sa] holds every row; r > 1: rows i*r only (the reference's csa, fmidx.c:153-163)
+    uint64_t reserved[10];
 };
 static_assert(sizeof(LrmBlobHeader) == 256, "header is 256 B");
 
@@ -70,9 +72,11 @@ struct LrmIndexView {
     uint64_t c4[4];
     int32_t hlen, mta_len;
     const uint64_t *lcl;      // optional LONG table (hl-mers, hl > hlen), built on the device from lc + FM steps; null = unused
-    int32_t hl, pad_;
+    int32_t hl;
+    int32_t sa_shift;         // log2 of the SA sampling ratio (0: every row is stored)
 };
 
+struct LrmHostCtx;            // lrm_host.hip: per-handle state of the host-buffer entry points
 struct lrm_index {
     void *d_blob;
     uint64_t blob_bytes;
@@ -83,6 +87,12 @@ struct lrm_index {
     uint64_t *d_lcl;          // long lc table (owned; may be null)
     uint64_t *d_cpl;          // planar 2-bit copy of the text for the bit-sliced GACT kernel (owned; may be null)
     int cpl_ok;               // text is pure ACGT (otherwise the byte kernels are used)
+    uint64_t *d_sas;          // sampled-SA locate mode (csa_access, fmidx.c:315-331): SA rows i*sa_ratio (owned; may be null)
+    LrmHostCtx *host;         // workspace, device mirrors, pinned staging and streams of the host-buffer calls (owned, lazy)
+    // multi-GPU group (lrm_index_upload_multi): replica r lives on its own device; peers[0] == this.  A batch call
+    // on the group handle partitions the reads by bases and runs one host thread per replica.
+    int n_peers;
+    lrm_index **peers;
 };
 
 // Per-(read,phase) vote result written by the vote kernels.
@@ -96,9 +106,13 @@ struct LrmDevCounters {
     unsigned long long reserved[8];
     unsigned long long decided_phase0;
     unsigned long long gact_tiles;
-    unsigned long long error_flags;
-    unsigned long long pad;
+    unsigned long long pad[2];
 };
+// Error word of a workspace: ONE dword of host-coherent pinned memory that kernels set with a plain store (bit 0:
+// vote table overflow in the multi-pass tier).  It is never cleared by a launch, so an error raised by any
+// sub-batch survives until the host reads it: lrm_workspace_stats and every *_dev entry point check it (the
+// next call after the faulty batch fails), the host-buffer entry points check it per sub-batch.
+#define LRM_ERR_VOTE_OVERFLOW 1u
 
 enum LrmKernelId { LRM_K_PACK2BIT = 0, LRM_K_SEED_SEARCH, LRM_K_VOTE, LRM_K_VOTE_WAVE2, LRM_K_DECIDE,
                    LRM_K_LOCUS, LRM_K_REVCOMP, LRM_K_GACT, LRM_K_VOTE_BLOCK, LRM_K_PACK_PLANAR, LRM_K_GACT_BS,
@@ -127,6 +141,8 @@ struct lrm_workspace {
     uint8_t *d_decided;      // n_max
     uint32_t *d_hcount;      // hits per (read, phase): routes an item to its vote-table tier
     LrmDevCounters *d_counters;
+    volatile uint32_t *h_err;   // error word (pinned host memory) and its device alias
+    uint32_t *d_err;
     // bit-sliced GACT: planar reads (wpr words per read) and per-read "byte other than ACGT" flags
     uint64_t *d_qpl;
     uint64_t qpl_wpr;
@@ -162,6 +178,9 @@ int lrm_lcl_prepare_index(lrm_index *idx);       // seed_kernels.hip: the long s
 void lrm_bs_free_index(lrm_index *idx);
 
 void lrm_set_error(const char *fmt, ...);
+int lrm_require_device(int device);
+int lrm_ws_take_error(lrm_workspace *ws);        // -2 + message if a kernel raised the workspace's sticky error word
+void lrm_host_ctx_free(lrm_index *idx);          // lrm_host.hip            // hipSetDevice + "no CPU fallback" error
 void lrm_time_begin(lrm_workspace *ws, int kernel, void *stream);
 void lrm_time_end(lrm_workspace *ws, void *stream);
 

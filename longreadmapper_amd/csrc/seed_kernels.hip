@@ -78,6 +78,35 @@ __device__ __forceinline__ void occ_rank2(const LrmIndexView &ix, uint32_t c, ui
     rb = eb.x + (uint64_t) __popcll(eb.y & (qb == 63u ? ~0ull : ((2ull << qb) - 1ull)));
 }
 
+// SA[row].  Full SA: one 8-byte gather (sa_access, fmidx.c:18-33).  Sampled SA (LRM_SA_SAMPLED=r): only rows
+// i*r are stored -- the reference's csa table (fmidx.c:153-163) -- and the other rows walk LF steps until
+// they reach a stored row or the '$' row: SA[row] = SA[LF^t(row)] + t (csa_access, fmidx.c:315-331).  The
+// bwt symbol of a row is the symbol whose occurrence mask holds the row's bit; the masks of the four symbols
+// of a block share one 64-byte line.  The reference's own LF step there subtracts one row too many
+// (fmidx.c:323, `- 1` on top of the inclusive rank: its walk leaves the text order and gives up after 5*ratio
+// steps); this is the textbook LF, so that the locate equals sa_access on every row -- the two modes of this
+// library give identical results, and csa_access itself is never called on the reference's hot path.
+__device__ __forceinline__ uint64_t sa_locate(const LrmIndexView &ix, uint64_t row) {
+    if (ix.sa_shift == 0) return ix.sa[row];
+    const uint64_t rmask = (1ull << ix.sa_shift) - 1ull;
+    uint64_t t = 0;
+    while (row & rmask) {
+        if (row == ix.dollar_row) return t;                             // SA[row] == 0
+        const LrmOccBlock *b = &ix.occ[row >> 6];
+        const uint32_t r = (uint32_t) row & 63u;
+        const ulonglong2 e0 = *reinterpret_cast<const ulonglong2 *>(&b->sym[0]);
+        const ulonglong2 e1 = *reinterpret_cast<const ulonglong2 *>(&b->sym[1]);
+        const ulonglong2 e2 = *reinterpret_cast<const ulonglong2 *>(&b->sym[2]);
+        const ulonglong2 e3 = *reinterpret_cast<const ulonglong2 *>(&b->sym[3]);
+        const uint32_t c = (uint32_t) ((e1.y >> r) & 1ull) | ((uint32_t) ((e2.y >> r) & 1ull) << 1) | ((uint32_t) ((e3.y >> r) & 1ull) * 3u);
+        const ulonglong2 e = c == 0 ? e0 : c == 1 ? e1 : c == 2 ? e2 : e3;
+        const uint64_t upto = r == 63u ? ~0ull : ((2ull << r) - 1ull);
+        row = ix.c4[c] + e.x + (uint64_t) __popcll(e.y & upto);         // LF(row) = C[c] + rank(c, row)
+        ++t;
+    }
+    return ix.sa[row >> ix.sa_shift] + t;
+}
+
 // lc_access (lchash.c:12-16) on the 8-byte device entries
 __device__ __forceinline__ void lc_lookup(const LrmIndexView &ix, uint64_t code, uint64_t &k, uint64_t &l) {
     const uint64_t e = ix.lc[code];
@@ -412,7 +441,7 @@ __device__ __forceinline__ bool vote_big_seeds(const LrmIndexView &ix, const Vot
 #pragma unroll
                 for (int u = 0; u < BIG_U; ++u) {
                     const uint32_t tt = base + (uint32_t) u * 64 + (uint32_t) lane;
-                    v[g][u] = tt < rs[g] ? ix.sa[ks[g] + tt] : 0ull;
+                    v[g][u] = tt < rs[g] ? sa_locate(ix, ks[g] + tt) : 0ull;
                 }
 #pragma unroll
             for (int g = 0; g < BIG_GRP; ++g)
@@ -428,7 +457,7 @@ __device__ __forceinline__ bool vote_big_seeds(const LrmIndexView &ix, const Vot
 
 __device__ __forceinline__ void load_small_hits(const LrmIndexView &ix, uint32_t rr, uint64_t k, uint64_t (&sv)[4]) {
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) sv[tt] = (rr <= 4 && (uint32_t) tt < rr) ? ix.sa[k + (uint32_t) tt] : 0ull;
+    for (int tt = 0; tt < 4; ++tt) sv[tt] = (rr <= 4 && (uint32_t) tt < rr) ? sa_locate(ix, k + (uint32_t) tt) : 0ull;
 }
 
 __device__ __forceinline__ bool vote_small_hits(const VoteTable &t, uint32_t rr, const uint64_t (&sv)[4], uint32_t q,
@@ -614,7 +643,7 @@ __global__ __launch_bounds__(256) void vote_block_kernel(LrmIndexView ix, const 
                                                          LrmPhaseRes *__restrict__ phase_res,
                                                          const uint32_t *__restrict__ hcount, uint32_t slots,
                                                          uint32_t limit, uint32_t lim_lo, uint32_t tbits,
-                                                         unsigned long long *err_flags) {
+                                                         uint32_t *err_word) {
     extern __shared__ __attribute__((aligned(16))) uint8_t vsmem[];
     __shared__ Cand s_c1[4], s_c2[4];
 
@@ -661,7 +690,7 @@ __global__ __launch_bounds__(256) void vote_block_kernel(LrmIndexView ix, const 
                 const uint64_t e = q < cnt ? r[q] : 0ull;
                             ok &= vote_chunk(ix, t, e, q, iter, (uint32_t) P, tbits, lane, passes, pass);
             }
-            if (!ok) atomicOr(err_flags, 1ull);
+            if (!ok) *(volatile uint32_t *) err_word = LRM_ERR_VOTE_OVERFLOW;   // host-coherent, sticky
             __syncthreads();
             Cand b1 = {0u, EMPTY32, 0u}, b2 = {0u, EMPTY32, 0u};
             for (uint32_t s = tid; s < t.slots; s += 256) {
@@ -831,6 +860,15 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
         lrm_time_begin(ws, LRM_K_VOTE_WAVE2, stream);
         {
             size_t sh3 = (size_t) T3_SLOTS * 20;
+            uint32_t t3_limit = T3_LIMIT, t3_slots = T3_SLOTS;
+            if (const char *e = getenv("LRM_T3_LIMIT")) {        // test knobs: a pass limit above the table size and a
+                const long long v = atoll(e);                     // small table force overflows of the multi-pass tier
+                if (v >= 1) t3_limit = (uint32_t) v;
+            }
+            if (const char *e = getenv("LRM_T3_SLOTS")) {
+                const long long v = atoll(e);
+                if (v >= 8 && v <= T3_SLOTS) t3_slots = (uint32_t) v;
+            }
             if (items > 0x7fffffffull) { lrm_set_error("vote grid too large: split the batch"); return -1; }
             hipLaunchKernelGGL(vote_wave2_kernel<T2A_SLOTS>, dim3((uint32_t) items), dim3(64), 0, stream, idx->view,
                                ws->d_rec, d_lens, dec, n, (int) seed_len, lo, hi, cap_q, tbits, (uint32_t) T1_LIMIT,
@@ -843,8 +881,7 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
             uint64_t b3 = (items + T3_GROUP - 1) / T3_GROUP;
             hipLaunchKernelGGL(vote_block_kernel, dim3((uint32_t) b3), dim3(256), sh3, stream, idx->view, ws->d_rec,
                                d_lens, dec, n, (int) seed_len, lo, hi, cap_q, ws->d_phase, ws->d_hcount,
-                               (uint32_t) T3_SLOTS, (uint32_t) T3_LIMIT, (uint32_t) T2W_LIMIT, tbits,
-                               &ws->d_counters->error_flags);
+                               t3_slots, t3_limit, (uint32_t) T2W_LIMIT, tbits, ws->d_err);
         }
         lrm_time_end(ws, stream);
         lrm_time_begin(ws, LRM_K_DECIDE, stream);

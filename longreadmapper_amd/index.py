@@ -102,7 +102,10 @@ class HostIndex:
         return _np_view(self.h.sa.mem, int(self.h.sa.len), np.uint64)
 
     def sa(self):
-        return self.sa_raw() & np.uint64((1 << 40) - 1)
+        """SA values as uint64 -- a VIEW of the ui40 slots (no copy: 50 GB for GRCh38).  The builder and the .sa5
+        reader of this library zero the three padding bytes of every 8-byte slot, so the slot read as a
+        little-endian u64 is the value."""
+        return self.sa_raw()
 
     def content(self):
         return _np_view(self.h.content, int(self.h.con_len), np.uint8)
@@ -139,6 +142,21 @@ class DeviceIndex:
                                    host.h.content, host.h.con_len, host.h.mta, host.h.mta_len, device),
               "lrm_index_upload")
         return cls(hnd)
+
+    @classmethod
+    def upload_multi(cls, host: HostIndex, devices):
+        """Multi-GPU group handle (lrm_index_upload_multi): one image per listed device, replicated over xGMI;
+        the batch calls shard the reads over the replicas."""
+        hnd = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        check(lib.lrm_index_upload_multi(C.byref(hnd), C.byref(host.h.fmi), C.byref(host.h.lch), C.byref(host.h.sa),
+                                         host.h.content, host.h.con_len, host.h.mta, host.h.mta_len, devs,
+                                         len(devices)), "lrm_index_upload_multi")
+        return cls(hnd)
+
+    @property
+    def replicas(self):
+        return int(lib.lrm_index_replicas(self.handle))
 
     @classmethod
     def upload_blob(cls, blob: np.ndarray, device=0):

@@ -51,8 +51,47 @@ def extend_batch(index, reads, lens, best, gact=DEFAULT_GACT):
     check(lib.lrm_extend_batch(index.handle, reads.ctypes.data, stride, lens.ctypes.data, n, best.ctypes.data, gp,
                                C.cast(cig, C.c_void_p), store.ctypes.data, store_stride, score.ctypes.data,
                                meta.ctypes.data, meta_r.ctypes.data), "lrm_extend_batch")
-    n_ops = np.array([cig[i].n_cigar_op for i in range(n)], dtype=np.int32)
+    n_ops = np.ctypeslib.as_array(C.cast(cig, C.POINTER(C.c_int32)), shape=(max(n, 1), 4))[:n, 2].copy()
     return dict(ops=store, n_ops=n_ops, score=score, meta=meta, meta_r=meta_r)
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """numpy array in pinned host memory (lrm_host_alloc): the DMA engines read / write it directly.
+    Free with pinned_free(arr)."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = lib.lrm_host_alloc(max(n, 1))
+    if not p:
+        raise capi.LrmError("lrm_host_alloc: " + lib.lrm_last_error().decode(errors="replace"))
+    buf = (C.c_char * max(n, 1)).from_address(p)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    return arr
+
+
+def pinned_free(arr):
+    lib.lrm_host_free(arr.ctypes.data)
+
+
+def map_batch(index, reads, lens, seed_len=DEFAULT_SEED_LEN, thres=DEFAULT_THRES, gact=DEFAULT_GACT, store=None):
+    """PART 1 + PART 2 in one device pass (lrm_map_batch); `reads` is modified in place like extend_batch.
+    `store` may be a caller-provided (n, >= 2*max_len) uint8 array (e.g. pinned)."""
+    assert reads.dtype == np.uint8 and reads.flags.c_contiguous and reads.flags.writeable
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    n, stride = reads.shape
+    max_len = int(lens.max()) if n else 0
+    if store is None:
+        store = np.zeros((n, max(2 * max_len, 1)), dtype=np.uint8)
+    store_stride = store.shape[1]
+    best = np.zeros(n, dtype=ENTRY_DT)
+    cig = (capi.Cigar * max(n, 1))()
+    score = np.zeros(n, dtype=np.int32)
+    meta = np.zeros(n, dtype=META_DT)
+    meta_r = np.zeros(n, dtype=np.int32)
+    check(lib.lrm_map_batch(index.handle, reads.ctypes.data, stride, lens.ctypes.data, n,
+                            capi.Params(n, seed_len, thres), capi.GactParams(*gact), best.ctypes.data,
+                            C.cast(cig, C.c_void_p), store.ctypes.data, store_stride, score.ctypes.data,
+                            meta.ctypes.data, meta_r.ctypes.data), "lrm_map_batch")
+    n_ops = np.ctypeslib.as_array(C.cast(cig, C.POINTER(C.c_int32)), shape=(max(n, 1), 4))[:n, 2].copy()
+    return dict(best=best, ops=store, n_ops=n_ops, score=score, meta=meta, meta_r=meta_r)
 
 
 def result_flags(score, meta_r, meta):

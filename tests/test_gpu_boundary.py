@@ -1,0 +1,210 @@
+"""GPU tests of the drop-in boundary beyond the two per-part calls: the fused one-pass call, pinned caller
+buffers, the sticky kernel-error word, multi-GPU group handles, the sampled-SA locate mode and suffix-array
+values beyond 32 bits.  Everything goes through the C-ABI (ctypes) and is compared with the CPU oracle."""
+import numpy as np
+import pytest
+
+import orc
+import workloads
+from longreadmapper_amd import capi, index, mapper, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_ext_equal(got, want, n, what=""):
+    assert np.array_equal(got["meta_r"], want["meta_r"]), what
+    for f in ("loc", "off", "seq_id", "strand"):
+        assert np.array_equal(got["meta"][f], want["meta"][f]), (what, f)
+    assert np.array_equal(got["score"], want["score"]), what
+    assert np.array_equal(got["n_ops"], want["n_ops"]), what
+    for i in range(n):
+        k = int(want["n_ops"][i])
+        assert bytes(got["ops"][i, :k]) == bytes(want["ops"][i, :k]), (what, i)
+
+
+@pytest.fixture(scope="module")
+def ont(gpu):
+    sc = workloads.scenario("ont-2k")
+    di = index.DeviceIndex.upload(sc["hi"], gpu)
+    oi = orc.OracleIndex.from_host_index(sc["hi"])
+    best, _ = oi.seed_batch(sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+    r_cpu = sc["reads"].copy()
+    ext = oi.extend_batch(r_cpu, sc["lens"], best)
+    yield sc, di, oi, best, ext, r_cpu
+    di.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"LRM_HOST_SUBS": "4"}, {"LRM_HOST_SLICE": "9", "LRM_HOST_SUBS": "2"}])
+def test_map_batch_equals_the_two_calls_and_the_oracle(ont, monkeypatch, env):
+    """lrm_map_batch = lrm_seed_batch + lrm_extend_batch in one device pass (one upload of the reads)."""
+    sc, di, oi, best, ext, r_cpu = ont
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    r = sc["reads"].copy()
+    got = mapper.map_batch(di, r, sc["lens"], sc["seed_len"], sc["thres"])
+    assert np.array_equal(got["best"], best)
+    _assert_ext_equal(got, ext, len(best), str(env))
+    assert np.array_equal(r, r_cpu)                      # reverse-strand reads rev-comped in the caller's buffer
+
+
+def test_map_batch_with_pinned_caller_buffers(ont):
+    """Buffers from lrm_host_alloc are handed to the DMA engines directly (no staging copy): same results."""
+    sc, di, oi, best, ext, r_cpu = ont
+    n, stride = sc["reads"].shape
+    r = mapper.pinned_empty((n, stride))
+    store = mapper.pinned_empty((n, 2 * (stride - 1)))
+    try:
+        r[:] = sc["reads"]
+        store[:] = 0
+        got = mapper.map_batch(di, r, sc["lens"], sc["seed_len"], sc["thres"], store=store)
+        assert np.array_equal(got["best"], best)
+        _assert_ext_equal(got, ext, n, "pinned")
+        assert np.array_equal(r, r_cpu)
+        # registered caller memory (what a maintainer does with the malloc'd buffers of alnmain.c:297-320)
+        r2 = np.ascontiguousarray(sc["reads"].copy())
+        capi.check(capi.lib.lrm_host_register(r2.ctypes.data, r2.nbytes), "lrm_host_register")
+        try:
+            got2 = mapper.map_batch(di, r2, sc["lens"], sc["seed_len"], sc["thres"])
+        finally:
+            capi.check(capi.lib.lrm_host_unregister(r2.ctypes.data), "lrm_host_unregister")
+        assert np.array_equal(got2["best"], best) and np.array_equal(r2, r_cpu)
+        _assert_ext_equal(got2, ext, n, "registered")
+    finally:
+        mapper.pinned_free(r)
+        mapper.pinned_free(store)
+
+
+def test_vote_overflow_is_reported_from_any_sub_batch(gpu, monkeypatch):
+    """LRM_T3_LIMIT above the table size forces the multi-pass tier into one pass and LRM_T3_SLOTS shrinks its
+    table: items with more distinct buckets than slots overflow.  The error word is sticky, so an overflow in sub-batch 0 of 4 fails the call
+    (it used to be erased by the next launch), and a *_dev caller gets it on the next call."""
+    import torch
+    sc = dict(workloads.scenario("repeats-overflow"))
+    di = index.DeviceIndex.upload(sc["hi"], gpu)
+    n = len(sc["lens"])
+    # only sub-batch 0 of 4 can overflow: reads 10.. are replaced by random sequences (no seed hits at all)
+    reads = sc["reads"].copy()
+    rnd = synth.reference(reads.shape[1] * (n - 10), seed=77).reshape(n - 10, reads.shape[1])
+    for i in range(10, n):
+        reads[i, :sc["lens"][i]] = rnd[i - 10, :sc["lens"][i]]
+    sc["reads"] = reads
+    try:
+        monkeypatch.setenv("LRM_T3_LIMIT", "1000000")
+        monkeypatch.setenv("LRM_T3_SLOTS", "64")
+        monkeypatch.setenv("LRM_HOST_SUBS", "4")
+        with pytest.raises(capi.LrmError, match="vote table overflow"):
+            mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+        # the handle stays usable and the flag does not leak into the next (good) batch
+        monkeypatch.delenv("LRM_T3_LIMIT")
+        monkeypatch.delenv("LRM_T3_SLOTS")
+        oi = orc.OracleIndex.from_host_index(sc["hi"])
+        want, _ = oi.seed_batch(sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+        got = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+        assert np.array_equal(got, want)
+        # device-buffer API: the faulty batch returns 0 (asynchronous), the next call on the workspace fails
+        monkeypatch.setenv("LRM_T3_LIMIT", "1000000")
+        monkeypatch.setenv("LRM_T3_SLOTS", "64")
+        stride = sc["reads"].shape[1]
+        dm = mapper.DeviceMapper(di, n, stride - 1, sc["seed_len"], sc["thres"], device=gpu)
+        d_reads = torch.from_numpy(sc["reads"]).cuda()
+        d_lens = torch.from_numpy(sc["lens"].astype(np.int32)).cuda()
+        dm.seed(d_reads, d_lens)
+        torch.cuda.synchronize()
+        monkeypatch.delenv("LRM_T3_LIMIT")
+        monkeypatch.delenv("LRM_T3_SLOTS")
+        with pytest.raises(capi.LrmError, match="vote table overflow"):
+            dm.seed(d_reads, d_lens)
+        dm.seed(d_reads, d_lens)                         # cleared by the failing call
+        torch.cuda.synchronize()
+        assert np.array_equal(dm.results(n)["best"], want)
+        dm.close()
+    finally:
+        di.close()
+
+
+@pytest.mark.parametrize("ngpus", [2, 3])
+def test_multi_gpu_group_handle_equals_one_gpu(ont, gpu, ngpus):
+    """lrm_index_upload_multi with the one visible device listed N times: N logical replicas, the batch is cut
+    into N slices by bases, one host thread per replica, results written in place -- byte-identical with N=1.
+    (Real multi-device runs are the driver's; this covers the code path and the partition.)"""
+    sc, di, oi, best, ext, r_cpu = ont
+    dg = index.DeviceIndex.upload_multi(sc["hi"], [gpu] * ngpus)
+    try:
+        assert dg.replicas == ngpus
+        # ragged lengths so that "by bases" differs from "by reads"
+        lens = sc["lens"].copy()
+        lens[: len(lens) // 3] //= 4
+        reads = sc["reads"].copy()
+        for i, l in enumerate(lens):
+            reads[i, l:] = 0
+        b1 = mapper.seed_batch(di, reads, lens, sc["seed_len"], sc["thres"])
+        bN = mapper.seed_batch(dg, reads, lens, sc["seed_len"], sc["thres"])
+        assert np.array_equal(b1, bN)
+        r1, rN, rM = reads.copy(), reads.copy(), reads.copy()
+        e1 = mapper.extend_batch(di, r1, lens, b1)
+        eN = mapper.extend_batch(dg, rN, lens, bN)
+        _assert_ext_equal(eN, e1, len(lens), "extend on the group")
+        assert np.array_equal(r1, rN)
+        m = mapper.map_batch(dg, rM, lens, sc["seed_len"], sc["thres"])
+        assert np.array_equal(m["best"], b1) and np.array_equal(rM, r1)
+        _assert_ext_equal(m, e1, len(lens), "map on the group")
+        want, _ = oi.seed_batch(reads, lens, sc["seed_len"], sc["thres"])
+        assert np.array_equal(b1, want)
+    finally:
+        dg.close()
+
+
+@pytest.mark.parametrize("name", ["ont-2k", "repeats-ties", "repeats-overflow", "ragged"])
+@pytest.mark.parametrize("ratio", ["4", "32"])
+def test_sampled_sa_locate_mode(gpu, monkeypatch, name, ratio):
+    """LRM_SA_SAMPLED=r keeps SA rows i*r only (the reference's csa table, fmidx.c:153-163) and locates the
+    rest by LF steps on the device (csa_access, fmidx.c:315-331, with the textbook LF -- see seed_kernels.hip):
+    identical best[] to the full-SA mode and to the oracle, with 1/r of the SA bytes in HBM."""
+    sc = workloads.scenario(name)
+    oi = orc.OracleIndex.from_host_index(sc["hi"])
+    want, _ = oi.seed_batch(sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+    full = sc["hi"].blob_bytes()
+    monkeypatch.setenv("LRM_SA_SAMPLED", ratio)
+    assert sc["hi"].blob_bytes() < full
+    di = index.DeviceIndex.upload(sc["hi"], gpu)
+    monkeypatch.delenv("LRM_SA_SAMPLED")
+    try:
+        got = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+        assert np.array_equal(got, want)
+    finally:
+        di.close()
+
+
+def test_suffix_array_values_beyond_32_bits(gpu):
+    """GRCh38's .cat has 6.2 G rows: SA values need ui40.high (sa_use.h:17-29).  A small FM index whose SA values
+    are all shifted by 2^33 + 2^36 pushes 37-bit values through lrm_index_upload (ui40 -> u64), the SA gathers,
+    the u64 diagonals, the LDS vote keys / buckets and best[] -- compared with the oracle on the same shifted SA."""
+    seqs = [synth.reference(150_000, seed=21)]
+    hi = index.HostIndex.build(seqs, o_ratio=32, hlen=8)
+    shift = (1 << 33) + (1 << 36)
+    raw = hi.sa_raw()
+    raw += np.uint64(shift)                              # ui40 {low, high}: bits 32..39 are `high`
+    assert int(hi.sa().min()) >= shift
+    r = synth.reads(seqs, 48, 1500, synth.ONT, seed=5)
+    oi = orc.OracleIndex.from_host_index(hi)
+    want, _ = oi.seed_batch(r["reads"], r["lens"], 20, 300)
+    assert (want["key"] >= np.uint64(1 << 33)).sum() > 40
+    di = index.DeviceIndex.upload(hi, gpu)
+    try:
+        got = mapper.seed_batch(di, r["reads"], r["lens"], 20, 300)
+        assert np.array_equal(got, want)
+    finally:
+        di.close()
+    # the same through the sampled-SA mode (values are added to LF step counts after the gather)
+    import os
+    os.environ["LRM_SA_SAMPLED"] = "4"
+    try:
+        di = index.DeviceIndex.upload(hi, gpu)
+    finally:
+        del os.environ["LRM_SA_SAMPLED"]
+    try:
+        # sampled rows hold shifted values; unsampled rows add their step count: still the shifted SA
+        got = mapper.seed_batch(di, r["reads"], r["lens"], 20, 300)
+        assert np.array_equal(got, want)
+    finally:
+        di.close()

@@ -137,3 +137,57 @@ def test_pack_blob_rejects_inconsistent_index():
     hi.o()[5] += 1
     with pytest.raises(capi.LrmError, match="O table disagrees"):
         hi.pack_blob()
+
+
+def _sa_with(algo, text, monkeypatch, scratch=None):
+    monkeypatch.setenv("LRM_SA_ALGO", algo)
+    if scratch:
+        monkeypatch.setenv("LRM_SA_SCRATCH_ROWS", str(scratch))
+    buf = np.frombuffer(text, dtype=np.uint8)
+    out = np.full(len(text), 0xA5A5A5A5A5A5A5A5, dtype=np.uint64)          # ui40 slots: 8 bytes each
+    assert capi.lib.lrm_sa_build(buf.ctypes.data, len(text), out.ctypes.data) == 0, capi.lib.lrm_last_error()
+    monkeypatch.delenv("LRM_SA_ALGO")
+    if scratch:
+        monkeypatch.delenv("LRM_SA_SCRATCH_ROWS")
+    return out
+
+
+def _sa_texts():
+    yield "random", bytes(synth.reference(300_000, seed=11)) + b"$"
+    yield "planted", bytes(synth.reference(400_000, seed=12, repeat_frac=0.3, rep_len=300, rep_copies=50, rep_div=0.02)) + b"$"
+    yield "ends-in-A-run", bytes(synth.reference(70_000, seed=13)) + b"A" * 100 + b"$"        # suffixes that run into '$' inside the key window
+    yield "poly-A", b"A" * 5000 + b"$"                                                           # every comparison ends at '$'
+    yield "tandem", b"ACGTTGCA" * 4000 + b"$"                                                    # long exact repeats: ties through the text
+    yield "exact-copies", bytes(synth.reference(3000, seed=14)) * 30 + b"$"
+    yield "tiny", b"GATTACA$"
+    yield "one", b"C$"
+    yield "empty", b"$"
+
+
+@pytest.mark.parametrize("name,text", list(_sa_texts()), ids=[n for n, _ in _sa_texts()])
+def test_parallel_suffix_sorter_equals_sais(monkeypatch, name, text):
+    """The bucketed parallel sorter (what GRCh38-sized texts need) against the linear-time SA-IS on the same text,
+    with a scratch so small that the buckets go through many groups; padding bytes of the ui40 slots are zeroed."""
+    want = _sa_with("sais", text, monkeypatch)
+    assert np.array_equal(np.sort(want), np.arange(len(text), dtype=np.uint64))
+    for scratch in (None, 1024):
+        got = _sa_with("bucket", text, monkeypatch, scratch)
+        assert np.array_equal(got, want), (name, scratch)
+
+
+def test_suffix_sorter_falls_back_on_repetitive_text(monkeypatch):
+    """Automatic mode: the tie budget sends a text of long exact repeats to SA-IS; a lower-case / non-ACGT text
+    takes the generic path at once.  Same suffix array either way."""
+    text = b"ACGTTGCA" * 30000 + b"$"
+    want = _sa_with("sais", text, monkeypatch)
+    buf = np.frombuffer(text, dtype=np.uint8)
+    out = np.zeros(len(text), dtype=np.uint64)
+    assert capi.lib.lrm_sa_build(buf.ctypes.data, len(text), out.ctypes.data) == 0
+    assert np.array_equal(out, want)
+    text = bytes(synth.reference(5000, seed=3)).lower() + b"NNNN" + bytes(synth.reference(100, seed=4)) + b"$"
+    buf = np.frombuffer(text, dtype=np.uint8)
+    out = np.zeros(len(text), dtype=np.uint64)
+    assert capi.lib.lrm_sa_build(buf.ctypes.data, len(text), out.ctypes.data) == 0
+    sa = out.astype(np.int64)
+    sufs = [text[i:] for i in sa[:200]]
+    assert sufs == sorted(sufs) and np.array_equal(np.sort(sa), np.arange(len(text)))
