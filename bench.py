@@ -8,9 +8,16 @@ ONT-profile reads, seed_len 20, thres 300 (reference defaults), GACT T=320 O=120
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched under torch.distributed.run)
 
-Rank 0 prints ONE JSON line.  Extra objects: "roofline" (dominant kernel, algorithmic bytes /
-HIP-event time vs 8 TB/s), "cpu_baseline" (the CPU oracle, OpenMP on the host cores, bounded
-sample of the same reads), "kernels" (per-kernel time and achieved algorithmic GB/s).
+Rank 0 prints ONE JSON line:
+  value            HBM-resident rate of the timed steps (the contract's `value`)
+  pcie_inclusive   SURVEY 8(d)'s metric: the same batch through the drop-in boundary lrm_map_batch on CALLER
+                   buffers -- H2D of the reads and D2H of every result inside the timed region -- with pinned
+                   (lrm_host_alloc) and with pageable (malloc, what alnmain.c has today) buffers
+  roofline         dominant kernel of a SERIALIZED replay of the same steps on one stream (every kernel has the
+                   chip to itself: kernel time <= step time), algorithmic bytes / HIP-event time vs 8 TB/s
+  cpu_baseline     the CPU oracle on a bounded sample of the same reads: all host cores and 1 thread
+                   (the reference's own configuration: both pragmas are commented out, alnmain.c:327-328)
+  kernels / isolated.kernels   per-kernel tables of the timed (overlapped) region and of the replay
 """
 import argparse
 import json
@@ -25,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 ECOLI_N = 4_641_652
 CHR1_N = 248_956_422
+GRCH38_N = 3_099_750_718    # GRCh38 primary assembly incl. unplaced scaffolds (no FASTA on the box: synthetic of this size)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -43,6 +51,11 @@ def usable_cpus():
     except (OSError, ValueError):
         pass
     return max(1, n)
+
+
+def peak_rss_gb():
+    import resource
+    return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
 
 
 def load_pmc_summary(args, n, Lr):
@@ -76,9 +89,10 @@ def main():
     ap.add_argument("--seed-len", type=int, default=20)
     ap.add_argument("--thres", type=int, default=300)
     ap.add_argument("--gact", default="320,120,128")
-    ap.add_argument("--isolated-replay", action="store_true",
-                    help="after the timed region, replay the steps serialized on one stream and report the per-kernel "
-                         "table of that replay under `isolated` (same as running --streams 1, in one invocation)")
+    ap.add_argument("--no-isolated-replay", action="store_true",
+                    help="skip the serialized replay of the steps on one stream that `roofline` is taken from")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg through lrm_map_batch")
+    ap.add_argument("--pcie-steps", type=int, default=0, help="steps of the PCIe-inclusive leg (default: min(steps, 8))")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("LRM_BENCH_STREAMS", "3")),
                     help="HIP streams the steps alternate over (each with its own workspace); >1 overlaps the "
                          "HBM-latency-bound seed kernels of one step with the VALU-bound extension of another")
@@ -105,11 +119,18 @@ def main():
     ref = synth.reference(args.ref_len, seed=1, repeat_frac=0.05, rep_len=300, rep_copies=1000, rep_div=0.05)
     hi = None
     blob = None
+    t_synth = time.time() - t0
+    t_build = t_pack = 0.0
     if rank == 0:
-        hi = index.HostIndex.build([ref], names=["synth_ecoli"], o_ratio=32, hlen=12)
-        t_build = time.time() - t0
-        blob = torch.from_numpy(hi.pack_blob()).to(dev)
-        log("index: N=%d L=%d built in %.1fs, image %.1f MiB" % (args.ref_len, hi.length, t_build, blob.numel() / 2**20))
+        t1 = time.time()
+        hi = index.HostIndex.build([ref], names=["synth_ref"], o_ratio=32, hlen=12)
+        t_build = time.time() - t1
+        t1 = time.time()
+        blob = hi.pack_device(local)          # packed piece by piece straight into HBM: no host copy of the image
+        torch.cuda.synchronize()
+        t_pack = time.time() - t1
+        log("index: N=%d L=%d: reference %.1fs, built in %.1fs, image %.2f GiB packed+uploaded in %.1fs"
+            % (args.ref_len, hi.length, t_synth, t_build, blob.numel() / 2**30, t_pack))
     t1 = time.time()
     blob = dist.broadcast_blob(blob, device=dev, src=0)
     torch.cuda.synchronize()
@@ -169,17 +190,60 @@ def main():
     # serialized replay of the same steps on ONE stream: per-kernel durations without the other streams' kernels
     # sharing the chip (the timed region above is what `value` and `roofline` come from)
     ktimes_iso = {}
-    if nstreams > 1 and args.isolated_replay and not args.no_kernel_timing and rank == 0:
+    iso_wall = None
+    if not args.no_isolated_replay and not args.no_kernel_timing and rank == 0:
+        torch.cuda.synchronize()
         slots[0]["dm"].set_timing(True)
+        ti = time.perf_counter()
         for _ in range(args.steps):
             with torch.cuda.stream(slots[0]["stream"]):
                 slots[0]["reads"].copy_(pristine)
                 slots[0]["dm"].seed(slots[0]["reads"], d_lens)
                 slots[0]["dm"].extend(slots[0]["reads"], d_lens)
         torch.cuda.synchronize()
+        iso_wall = time.perf_counter() - ti
         with torch.cuda.stream(slots[0]["stream"]):
             ktimes_iso = slots[0]["dm"].timing()
         slots[0]["dm"].set_timing(False)
+    # ---- the same batch through the drop-in boundary on caller buffers (H2D + D2H timed) ----------
+    pcie = None
+    if not args.no_pcie:
+        ps = args.pcie_steps or min(args.steps, 8)
+        stride = r["reads"].shape[1]
+        pcie = dict(steps=ps, entry_point="lrm_map_batch (seed + extend in one device pass; reads cross the link once)")
+        for kind in ("pinned", "pageable"):
+            if kind == "pinned":
+                hr = mapper.pinned_empty((n, stride))
+                hs = mapper.pinned_empty((n, 2 * Lr))
+            else:
+                hr = np.empty((n, stride), dtype=np.uint8)
+                hs = np.empty((n, 2 * Lr), dtype=np.uint8)
+            hs[:] = 0
+            hr[:] = r["reads"]
+            mapper.map_batch(di, hr, r["lens"], args.seed_len, args.thres, gact, store=hs)      # warm-up: device mirrors, workspace
+            barrier()
+            tp = 0.0
+            for _ in range(ps):
+                hr[:] = r["reads"]                                                             # untimed: the caller's batch load
+                barrier()
+                t1 = time.perf_counter()
+                res_p = mapper.map_batch(di, hr, r["lens"], args.seed_len, args.thres, gact, store=hs)
+                barrier()
+                tp += time.perf_counter() - t1
+            tq = torch.tensor([tp], dtype=torch.float64, device=dev if tdist.is_initialized() and tdist.get_backend() == "nccl" else "cpu")
+            if world > 1:
+                tdist.all_reduce(tq, op=tdist.ReduceOp.MAX)
+            pcie[kind] = dict(value=bases * world * ps / float(tq.item()) / 1e9, unit="Gbp/s", ms_per_step=float(tq.item()) / ps * 1e3)
+            if kind == "pinned":
+                pcie_res = dict(best=res_p["best"].copy(), score=res_p["score"].copy(), n_ops=res_p["n_ops"].copy())
+                mapper.pinned_free(hr)
+                mapper.pinned_free(hs)
+            del hr, hs
+        pcie["value"] = pcie["pinned"]["value"]
+        pcie["unit"] = "Gbp/s"
+        pcie["bytes_per_step"] = dict(h2d=int(n * stride + 4 * n), d2h_reads=int(n * stride),
+                                      d2h_ops="used columns of the op-byte buffer (n x max n_ops rounded to 64)")
+
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if tdist.is_initialized() and tdist.get_backend() == "nccl" else "cpu")
     if world > 1:
         tdist.all_reduce(tt, op=tdist.ReduceOp.MAX)
@@ -229,11 +293,29 @@ def main():
     cpu = dict(value=sample_bases / probe / 1e9, unit="Gbp/s", cores=cores, kind="port",
                sample="first %d reads of the batch (%d bases), seed+extend, %.1f s wall, OpenMP dynamic over reads"
                       % (sample_n, sample_bases, probe))
+    if args.cpu_seconds > 0:
+        # one thread: the reference's own configuration (both parallel pragmas are commented out, alnmain.c:327-328)
+        n1 = max(1, min(sample_n, int(sample_n * (args.cpu_seconds * 0.6) / max(probe * cores, 1e-3))))
+        r1 = np.ascontiguousarray(r["reads"][:n1]).copy()
+        tc = time.perf_counter()
+        b1, _ = oi.seed_batch(r1, r["lens"][:n1], args.seed_len, args.thres, nthreads=1)
+        oi.extend_batch(r1, r["lens"][:n1], b1, gact, nthreads=1)
+        t1c = time.perf_counter() - tc
+        b1n = int(r["lens"][:n1].sum())
+        cpu["one_thread"] = dict(value=b1n / t1c / 1e9, unit="Gbp/s", cores=1,
+                                 sample="first %d reads (%d bases), seed+extend, %.1f s wall" % (n1, b1n, t1c))
     # the oracle's output on the sample must equal the GPU's (same reads: the first sample_n of rank 0)
     gres = dm.results(min(sample_n, n))
     assert np.array_equal(gres["best"][:sample_n], best), "GPU best[] differs from the CPU oracle on the bench batch"
     assert np.array_equal(gres["score"][:sample_n], ext["score"]), "GPU scores differ from the CPU oracle"
     assert np.array_equal(gres["n_ops"][:sample_n], ext["n_ops"]), "GPU CIGAR lengths differ from the CPU oracle"
+    if pcie:                                     # ... and so must the results that came back through lrm_map_batch
+        assert np.array_equal(pcie_res["best"][:sample_n], best), "lrm_map_batch best[] differs from the CPU oracle"
+        assert np.array_equal(pcie_res["score"][:sample_n], ext["score"]) and np.array_equal(pcie_res["n_ops"][:sample_n], ext["n_ops"])
+        full = dm.results(n)
+        assert np.array_equal(pcie_res["best"], full["best"]) and np.array_equal(pcie_res["score"], full["score"]), \
+            "lrm_map_batch and the device-resident path disagree"
+        pcie["checked"] = "best[], score, n_ops of all %d reads equal the device-resident path; first %d equal the CPU oracle" % (n, sample_n)
     # algorithmic bytes per read base, counted exactly on the sample
     ce = ext["counters"]
     per_base = dict(
@@ -295,36 +377,49 @@ def main():
         return r
 
     kernels, dominant = kernel_table(ktimes)
-    roofline = roofline_of(kernels, ktimes, dominant) if dominant else None
-    if roofline and nstreams > 1:
-        roofline["overlap_note"] = ("steps alternate over %d HIP streams: this duration includes the time the kernel shared "
-                                    "the chip with kernels of other steps; `bench.py --streams 1` measures it alone "
-                                    "(profiles/r1/bench_streams1.json: seed_search 15.9 ms per launch, frac 0.48)" % nstreams)
-    roofline_hbm = roofline_of(kernels, ktimes, "seed_search_kernel") if "seed_search_kernel" in kernels else None
+    traffic_note = ("`traffic` = FETCH_SIZE + WRITE_SIZE per launch from the committed rocprofv3 --pmc passes of this workload "
+                    "(profiles/*/pmc_summary.json), not measured in this run; null for other workloads")
     isolated = None
     if ktimes_iso:
+        # the roofline comes from the serialized replay: every kernel has the chip to itself, so kernel time <= step time
         k_iso, dom_iso = kernel_table(ktimes_iso)
-        isolated = dict(note="serialized replay of the same %d steps on one stream after the timed region: per-kernel "
-                             "durations without kernels of other steps sharing the chip" % args.steps,
-                        ms_per_step=sum(v["ms_total"] for v in k_iso.values()) / args.steps,
-                        roofline=roofline_of(k_iso, ktimes_iso, dom_iso),
-                        roofline_hbm_kernel=roofline_of(k_iso, ktimes_iso, "seed_search_kernel"),
+        roofline = roofline_of(k_iso, ktimes_iso, dom_iso)
+        roofline["source"] = ("serialized replay of the same %d steps on ONE stream right after the timed region (HIP events on "
+                              "that stream); the timed region itself overlaps steps on %d streams" % (args.steps, nstreams))
+        roofline["traffic_source"] = traffic_note
+        roofline_hbm = roofline_of(k_iso, ktimes_iso, "seed_search_kernel") if "seed_search_kernel" in k_iso else None
+        isolated = dict(note="serialized replay: per-kernel durations without kernels of other steps sharing the chip",
+                        ms_per_step=iso_wall / args.steps * 1e3, value=bases * args.steps / iso_wall / 1e9,
+                        kernel_ms_per_step=sum(v["ms_total"] for v in k_iso.values()) / args.steps,
                         roofline_gact=roofline_of(k_iso, ktimes_iso, "gact_bs_kernel") if "gact_bs_kernel" in k_iso else None,
                         kernels=k_iso)
+    else:
+        roofline = roofline_of(kernels, ktimes, dominant) if dominant else None
+        roofline_hbm = roofline_of(kernels, ktimes, "seed_search_kernel") if "seed_search_kernel" in kernels else None
+        if roofline and nstreams > 1:
+            roofline["source"] = ("timed region, steps alternating over %d HIP streams: durations include the time a kernel "
+                                  "shared the chip with kernels of other steps" % nstreams)
     total_bases = bases * world * args.steps
     out = dict(metric="aligned Gbp/sec", value=total_bases / elapsed / 1e9, unit="Gbp/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u8/u64 integer", data="synthetic",
                config=dict(workload="%s synthetic reference (%d bp, 5%% planted repeats), "
                                     "%d x %d bp %s-profile reads per GPU"
-                                    % ({ECOLI_N: "E. coli K-12 sized", CHR1_N: "human chr1 sized"}.get(args.ref_len, "custom"),
+                                    % ({ECOLI_N: "E. coli K-12 sized", CHR1_N: "human chr1 sized",
+                                        GRCH38_N: "GRCh38 sized"}.get(args.ref_len, "custom"),
                                        args.ref_len, n, Lr, args.profile),
                            seed_len=args.seed_len, thres=args.thres, gact_T=gact[0], gact_O=gact[1], gact_W=gact[2],
                            reads_per_gpu=n, read_len=Lr, streams=nstreams, parallelism="reads sharded, index replicated (1 RCCL bcast)"),
-               roofline=roofline, roofline_hbm_kernel=roofline_hbm, cpu_baseline=cpu, kernels=kernels,
-               isolated=isolated, streams=nstreams,
+               roofline=roofline, roofline_hbm_kernel=roofline_hbm, cpu_baseline=cpu, pcie_inclusive=pcie,
+               value_note="HBM-resident: the batch is in device memory when the timed region starts (the contract's `value`); "
+                          "SURVEY 8(d)'s metric with H2D of reads and D2H of results timed is `pcie_inclusive`",
+               kernels=kernels, isolated=isolated, streams=nstreams,
                algorithmic_bytes_per_base=per_base, stats=stats,
-               index_broadcast_s=round(t_bcast, 3), speedup_vs_cpu=(total_bases / elapsed / 1e9) / cpu["value"])
+               index=dict(rows=hi.length, image_bytes=int(blob.numel()), reference_s=round(t_synth, 1), build_s=round(t_build, 1),
+                          pack_upload_s=round(t_pack, 1), broadcast_s=round(t_bcast, 3),
+                          host_cpus=usable_cpus(), peak_rss_gb=round(peak_rss_gb(), 1)),
+               speedup_vs_cpu=(total_bases / elapsed / 1e9) / cpu["value"],
+               speedup_pcie_inclusive_vs_cpu=(pcie["value"] / cpu["value"]) if pcie else None)
     print(json.dumps(out), flush=True)
     if world > 1:
         tdist.barrier()

@@ -105,10 +105,17 @@ int lrm_index_pack_blob(const lrm_dna_fmi *fmi, const lrm_lc_hash *lch,
                         const lrm_sa_mem *sa, const char *content, uint64_t con_len,
                         const lrm_mta_entry *mta, int mta_len, void *blob, uint64_t blob_bytes);
 
-/* One-call upload used behind alnmain.c:init(): pack + hipMemcpy to `device`. */
+/* One-call upload used behind alnmain.c:init(): the image is packed piece by piece into pinned chunks whose
+ * DMA overlaps the packing of the next piece -- no host copy of the image. */
 int lrm_index_upload(lrm_index **out, const lrm_dna_fmi *fmi, const lrm_lc_hash *lch,
                      const lrm_sa_mem *sa, const char *content, uint64_t con_len,
                      const lrm_mta_entry *mta, int mta_len, int device);
+
+/* pack straight into device memory the caller owns (blob_bytes >= lrm_index_blob_bytes()): no host copy of the
+ * image; the buffer can then be broadcast and adopted (lrm_index_adopt_device) on every rank. */
+int lrm_index_pack_device(const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
+                          const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len,
+                          void *d_blob, uint64_t blob_bytes, int device);
 
 /* Multi-GPU group: the image is packed once, uploaded to devices[0] and replicated to the other devices over
  * xGMI (one RCCL broadcast; hipMemcpyPeer if librccl cannot be loaded).  devices == NULL means 0..ngpus-1.  The
@@ -205,20 +212,20 @@ int lrm_extend_batch_dev(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint6
  * the stream): vote items per table tier, reads decided in
  * phase 0, GACT tiles.  For tests / bench bookkeeping only. */
 typedef struct lrm_stats {
-    uint64_t vote_tier2_items;      /* (read,phase) items voted with the 2048-slot workgroup table */
-    uint64_t vote_tier3_items;      /* ... with the multi-pass workgroup table */
+    uint64_t vote_tier2_items;      /* (read,phase) items voted by a whole workgroup in one pass (192 < hits <= 960) */
+    uint64_t vote_tier3_items;      /* ... in several passes over the workgroup table (hits > 960) */
     uint64_t reads_decided_phase0;  /* reads whose vote passed 0.6 in phase 0 */
     uint64_t gact_tiles;
 } lrm_stats;
 int lrm_workspace_stats(lrm_workspace *ws, lrm_stats *out, void *stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (bench bookkeeping).
- * Kernel order: pack2bit, seed_search, vote_wave (tier 1), vote_wave2 (tier 2), decide, locus_resolve,
- * revcomp, gact (byte kernels), vote_block (tier 3), bs_pack_reads, gact_bs (bit-sliced kernel).
+ * Kernel order: pack2bit, seed_search, vote, decide, locus_resolve, revcomp, gact (byte kernels),
+ * bs_pack_reads, gact_bs (bit-sliced kernel + expansion).
  * lrm_workspace_timing synchronises the stream, ADDS the elapsed milliseconds and launch counts
  * of everything recorded since the last call into ms[LRM_N_KERNELS] / launches[LRM_N_KERNELS], and
  * resets the record. */
-#define LRM_N_KERNELS 11
+#define LRM_N_KERNELS 9
 int lrm_workspace_set_timing(lrm_workspace *ws, int enable);
 int lrm_workspace_timing(lrm_workspace *ws, double *ms, uint64_t *launches, void *stream);
 const char *lrm_kernel_name(int kernel);

@@ -85,6 +85,8 @@ SYMBOLS = {
                                       C.c_uint64, C.POINTER(MtaEntry), C.c_int, C.c_void_p, C.c_uint64]),
     "lrm_index_upload": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(DnaFmi), C.POINTER(LcHash),
                                    C.POINTER(SaMem), C.c_void_p, C.c_uint64, C.POINTER(MtaEntry), C.c_int, C.c_int]),
+    "lrm_index_pack_device": (C.c_int, [C.POINTER(DnaFmi), C.POINTER(LcHash), C.POINTER(SaMem), C.c_void_p,
+                                        C.c_uint64, C.POINTER(MtaEntry), C.c_int, C.c_void_p, C.c_uint64, C.c_int]),
     "lrm_index_adopt_device": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_int]),
     "lrm_index_upload_blob": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_int]),
     "lrm_index_free": (None, [C.c_void_p]),

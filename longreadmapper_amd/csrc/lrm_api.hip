@@ -405,29 +405,20 @@ extern "C" int lrm_index_adopt_device(lrm_index **out, void *d_blob, uint64_t bl
 }
 
 // pack + upload without a host copy of the image: two pinned chunks, the DMA of one overlaps the packing of the other
-extern "C" int lrm_index_upload(lrm_index **out, const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
-                                const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len, int device) {
-    if (!out || !fmi || !lch) { lrm_set_error("null argument"); return -1; }
-    if (require_device(device)) return -1;
-    BlobPacker pk;
-    if (pk.init(fmi, lch, sa, content, con_len, mta, mta_len)) return -1;
-    if (mta_len > 0 && (uint64_t) mta_len * sizeof(LrmMtaDev) > LRM_PACK_PIECE) { lrm_set_error("too many sequences"); return -1; }
+static int stream_image(const BlobPacker &pk, void *d_dst) {
     struct Res {
-        void *d = nullptr; void *pin[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; hipStream_t st = nullptr;
+        void *pin[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; hipStream_t st = nullptr;
         ~Res() {
             if (st) { (void) hipStreamSynchronize(st); (void) hipStreamDestroy(st); }
             for (int i = 0; i < 2; ++i) { if (pin[i]) (void) hipHostFree(pin[i]); if (ev[i]) (void) hipEventDestroy(ev[i]); }
-            if (d) (void) hipFree(d);
         }
     } r;
-    const uint64_t bytes = pk.h.total_bytes;
-    if (hipMalloc(&r.d, bytes) != hipSuccess) { lrm_set_error("hipMalloc of the %llu-byte index image failed", (unsigned long long) bytes); return -1; }
-    HIPCHK(hipMemset(r.d, 0, sizeof(LrmBlobHeader)));
     HIPCHK(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
         HIPCHK(hipHostMalloc(&r.pin[i], LRM_PACK_PIECE, hipHostMallocDefault));
         HIPCHK(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming));
     }
+    HIPCHK(hipMemsetAsync(d_dst, 0, pk.h.total_bytes, r.st));          // alignment gaps: images of equal inputs are byte-identical
     uint64_t seq = 0;
     bool used[2] = {false, false};
     int rc = pk.emit(
@@ -438,7 +429,7 @@ extern "C" int lrm_index_upload(lrm_index **out, const lrm_dna_fmi *fmi, const l
         },
         [&](uint64_t off, uint64_t n, const uint8_t *buf) -> int {
             const int b = (int) (seq & 1);
-            HIPCHK(hipMemcpyAsync((uint8_t *) r.d + off, buf, n, hipMemcpyHostToDevice, r.st));
+            HIPCHK(hipMemcpyAsync((uint8_t *) d_dst + off, buf, n, hipMemcpyHostToDevice, r.st));
             HIPCHK(hipEventRecord(r.ev[b], r.st));
             used[b] = true;
             ++seq;
@@ -446,11 +437,36 @@ extern "C" int lrm_index_upload(lrm_index **out, const lrm_dna_fmi *fmi, const l
         });
     if (rc) return -1;
     HIPCHK(hipStreamSynchronize(r.st));
-    if (make_handle(out, r.d, bytes, device, 1, pk.h)) return -1;
-    r.d = nullptr;                 // owned by the handle now
     return 0;
 }
 
+extern "C" int lrm_index_upload(lrm_index **out, const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
+                                const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len, int device) {
+    if (!out || !fmi || !lch) { lrm_set_error("null argument"); return -1; }
+    if (require_device(device)) return -1;
+    BlobPacker pk;
+    if (pk.init(fmi, lch, sa, content, con_len, mta, mta_len)) return -1;
+    if (mta_len > 0 && (uint64_t) mta_len * sizeof(LrmMtaDev) > LRM_PACK_PIECE) { lrm_set_error("too many sequences"); return -1; }
+    const uint64_t bytes = pk.h.total_bytes;
+    void *d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) { (void) hipGetLastError(); lrm_set_error("hipMalloc of the %llu-byte index image failed", (unsigned long long) bytes); return -1; }
+    if (stream_image(pk, d) || make_handle(out, d, bytes, device, 1, pk.h)) { (void) hipFree(d); return -1; }
+    return 0;
+}
+
+// the same into device memory the caller owns (e.g. a buffer that is then broadcast to the other ranks and
+// adopted with lrm_index_adopt_device on every rank)
+extern "C" int lrm_index_pack_device(const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
+                                     const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len,
+                                     void *d_blob, uint64_t blob_bytes, int device) {
+    if (!fmi || !lch || !d_blob) { lrm_set_error("null argument"); return -1; }
+    if (require_device(device)) return -1;
+    BlobPacker pk;
+    if (pk.init(fmi, lch, sa, content, con_len, mta, mta_len)) return -1;
+    if (mta_len > 0 && (uint64_t) mta_len * sizeof(LrmMtaDev) > LRM_PACK_PIECE) { lrm_set_error("too many sequences"); return -1; }
+    if (blob_bytes < pk.h.total_bytes) { lrm_set_error("device buffer too small for the image"); return -1; }
+    return stream_image(pk, d_blob);
+}
 
 // ------------------------------------------------------------------------------------------
 // multi-GPU group: the image is packed and uploaded once (device devices[0]) and replicated to the other
@@ -591,7 +607,7 @@ extern "C" void lrm_workspace_free(lrm_workspace *ws) {
     if (!ws) return;
     (void) hipSetDevice(ws->device);
     (void) hipFree(ws->d_reads2); (void) hipFree(ws->d_rec); (void) hipFree(ws->d_phase); (void) hipFree(ws->d_decided);
-    (void) hipFree(ws->d_hcount); (void) hipFree(ws->d_counters);
+    (void) hipFree(ws->d_hcount); (void) hipFree(ws->d_counters); (void) hipFree(ws->d_recq); (void) hipFree(ws->d_cnt);
     (void) hipFree(ws->d_qpl); (void) hipFree(ws->d_rflags);
     (void) hipFree(ws->d_ckpt); (void) hipFree(ws->d_codes); (void) hipFree(ws->d_ncodes);
     if (ws->h_err) (void) hipHostFree((void *) ws->h_err);
@@ -626,6 +642,8 @@ extern "C" int lrm_workspace_create(lrm_workspace **out, lrm_index *idx, uint64_
     struct { void **p; uint64_t bytes; } allocs[] = {
         {(void **) &ws->d_reads2, n_max * ws->words_per_read * 8},
         {(void **) &ws->d_rec, n_max * (uint64_t) ws->P * ws->cap_q * 8},
+        {(void **) &ws->d_recq, n_max * (uint64_t) ws->P * ws->cap_q * 4},
+        {(void **) &ws->d_cnt, n_max * (uint64_t) ws->P * 4},
         {(void **) &ws->d_phase, n_max * (uint64_t) ws->P * sizeof(LrmPhaseRes)},
         {(void **) &ws->d_decided, n_max},
         {(void **) &ws->d_hcount, n_max * (uint64_t) ws->P * 4},
@@ -722,7 +740,7 @@ extern "C" int lrm_workspace_stats(lrm_workspace *ws, lrm_stats *out, void *stre
         std::vector<uint32_t> hc((size_t) ws->n_last * ws->P);
         if (!hc.empty()) HIPCHK(hipMemcpy(hc.data(), ws->d_hcount, hc.size() * 4, hipMemcpyDeviceToHost));
         uint64_t t2 = 0, t3 = 0;
-        for (uint32_t h : hc) { t2 += (h > 192 && h <= 768); t3 += (h > 768); }
+        for (uint32_t h : hc) { t2 += (h > 192 && h <= 960); t3 += (h > 960); }
         out->vote_tier2_items = t2;
         out->vote_tier3_items = t3;
     }
@@ -774,9 +792,8 @@ extern "C" int lrm_workspace_timing(lrm_workspace *ws, double *ms, uint64_t *lau
 }
 
 extern "C" const char *lrm_kernel_name(int k) {
-    static const char *names[LRM_K_COUNT] = {"pack2bit_kernel", "seed_search_kernel", "vote_wave_kernel",
-                                             "vote_wave2_kernel", "decide_kernel", "locus_resolve_kernel",
-                                             "revcomp_kernel", "gact_kernel", "vote_block_kernel",
+    static const char *names[LRM_K_COUNT] = {"pack2bit_kernel", "seed_search_kernel", "vote_kernel", "decide_kernel",
+                                             "locus_resolve_kernel", "revcomp_kernel", "gact_kernel",
                                              "bs_pack_reads_kernel", "gact_bs_kernel"};
     return k >= 0 && k < LRM_K_COUNT ? names[k] : "?";
 }

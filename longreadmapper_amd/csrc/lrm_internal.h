@@ -114,8 +114,8 @@ struct LrmDevCounters {
 // next call after the faulty batch fails), the host-buffer entry points check it per sub-batch.
 #define LRM_ERR_VOTE_OVERFLOW 1u
 
-enum LrmKernelId { LRM_K_PACK2BIT = 0, LRM_K_SEED_SEARCH, LRM_K_VOTE, LRM_K_VOTE_WAVE2, LRM_K_DECIDE,
-                   LRM_K_LOCUS, LRM_K_REVCOMP, LRM_K_GACT, LRM_K_VOTE_BLOCK, LRM_K_PACK_PLANAR, LRM_K_GACT_BS,
+enum LrmKernelId { LRM_K_PACK2BIT = 0, LRM_K_SEED_SEARCH, LRM_K_VOTE, LRM_K_DECIDE,
+                   LRM_K_LOCUS, LRM_K_REVCOMP, LRM_K_GACT, LRM_K_PACK_PLANAR, LRM_K_GACT_BS,
                    LRM_K_COUNT };
 #define LRM_MAX_TIMED 4096
 
@@ -136,10 +136,12 @@ struct lrm_workspace {
     uint64_t bytes;
     // device buffers
     uint64_t *d_reads2;      // packed reads
-    uint64_t *d_rec;         // per-seed records: n_max * P * cap_q
+    uint64_t *d_rec;         // survivor records k | rr << 40, compact per (read, phase): n_max * P * cap_q capacity
+    uint32_t *d_recq;        // seed ordinal q of every survivor record
+    uint32_t *d_cnt;         // survivors per (read, phase)
     LrmPhaseRes *d_phase;    // n_max * P
     uint8_t *d_decided;      // n_max
-    uint32_t *d_hcount;      // hits per (read, phase): routes an item to its vote-table tier
+    uint32_t *d_hcount;      // SA hits (sum of rr) per (read, phase): routes an item to its vote-table tier
     LrmDevCounters *d_counters;
     volatile uint32_t *h_err;   // error word (pinned host memory) and its device alias
     uint32_t *d_err;

@@ -5,9 +5,8 @@
 //
 // Decomposition (MI355X-first, not the reference's per-read loop nest):
 //   pack2bit      reads (1 B/base) -> 2 bit/base stream, so a seed is ONE bit-field window
-//   seed_search   one lane per seed: lc lookup + FM backward extension        (K1, HBM gathers)
-//   vote_wave / vote_wave2 / vote_block
-//                 one wavefront or workgroup per (read, phase): SA gather + LDS vote table, tiered by hit count (K2)
+//   seed_search   one lane per seed: lc lookup + FM backward extension; compact survivor lists   (K1, HBM gathers)
+//   vote          one wavefront or workgroup per (read, phase): flat hit expansion, SA gather, LDS vote table (K2)
 //   decide        one lane per read: the phase state machine of alnmain.c:371-403
 //
 // The reference evaluates phases one after another and stops at the first phase whose
@@ -221,43 +220,82 @@ __device__ __forceinline__ uint64_t read_window(const uint64_t *__restrict__ wor
 }
 
 // ----------------------------------------------------------------------------------------
-// K1 seed_search: one lane per seed.  Work items of a read are (q, iter) with iter fastest.
-// rec[read][iter][q] = k | rr<<40  when 0 < rr < thres, else 0.
+// K1 seed_search: one lane per seed, SS_ITEMS seeds per workgroup (4 per thread).  Work items of a read are
+// (q, iter) with iter fastest, so the 64 lanes of a wavefront hold 64 CONSECUTIVE read positions.
+// Output: the SURVIVORS only (0 < rr < thres, ~25 % of the seeds of a noisy read), compact per (read, phase):
+//   rec [id][0 .. cnt[id])   k | rr << 40         recq[id][..]  seed ordinal q        (id = read*P + phase)
+//   cnt [id]  survivors      hits[id]  sum of rr  (= SA rows the vote will gather; routes the item to its tier)
+// A workgroup appends its survivors to per-phase lists in LDS (LDS atomics), reserves room in the global lists with
+// ONE global atomic per phase and workgroup, and copies every list segment out with contiguous stores.  (The first
+// version stored an 8-byte record per seed POSITION, 75 % zeros, with scattered stores: 16.7 GB written per Gbp,
+// and every vote tier re-read all of it.)  The order of a list does not matter: the first-seen order key of a hit,
+// (q << tbits) | t, is a property of the hit.
 // ----------------------------------------------------------------------------------------
+#define SS_ITEMS 1024
 __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const uint64_t *__restrict__ reads2,
                                                           uint64_t words_per_read,
                                                           const uint32_t *__restrict__ lens,
                                                           const uint8_t *__restrict__ decided, uint64_t n,
                                                           int seed_len, uint32_t thres, int phase_lo, int phase_hi,
                                                           uint32_t cap_q, uint32_t blocks_per_read,
-                                                          uint64_t *__restrict__ rec) {
-    uint64_t read = blockIdx.x / blocks_per_read;
-    uint32_t chunk = blockIdx.x % blocks_per_read;
+                                                          uint64_t *__restrict__ rec, uint32_t *__restrict__ recq,
+                                                          uint32_t *__restrict__ gcnt, uint32_t *__restrict__ ghits) {
+    __shared__ uint64_t s_rec[SS_ITEMS + 64];
+    __shared__ uint32_t s_q[SS_ITEMS + 64];
+    __shared__ uint32_t s_cnt[64], s_hits[64], s_base[64];
+    const uint64_t read = blockIdx.x / blocks_per_read;
+    const uint32_t chunk = blockIdx.x % blocks_per_read;
     if (read >= n) return;
     if (decided && decided[read]) return;
     const int P = seed_len + 1;
-    const int np = phase_hi - phase_lo + 1;
-    // iter fastest: the 64 lanes of a wavefront hold 64 CONSECUTIVE read positions.  Neighbouring
-    // seeds overlap, so they share their fate (a sequencing error kills ~20 consecutive seeds, a clean
-    // stretch lets all of them run the full backward extension): wavefronts diverge little.
-    // Measured alternatives that lost: q fastest (coalesced record stores, but every wavefront mixes
-    // dead and live lanes: +26 %), two seeds per lane (+26 %), lane refill from a work chunk (+13 %),
-    // packing the survivors of the table lookup into the workgroup's first wavefronts through LDS (+8 %):
-    // the kernel is bound by the rate of memory requests, not by idle lanes or wavefront slots.
-    uint32_t item = chunk * 256 + threadIdx.x;
-    uint32_t q = item / (uint32_t) np;
-    int iter = phase_lo + (int) (item % (uint32_t) np);
-    if (q >= cap_q) return;
-    uint32_t len = lens[read];
-    uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;   // alnmain.c:353 (fenced for len<s)
-    uint64_t j = (uint64_t) iter + (uint64_t) q * (uint64_t) P;
-    uint64_t *out = rec + (read * (uint64_t) P + (uint64_t) iter) * cap_q + q;
-    if (j >= jl) { __builtin_nontemporal_store(0ull, out); return; }
-    uint64_t win = read_window(reads2 + read * words_per_read, (uint32_t) j);
-    uint64_t k, l;
-    uint64_t rr = seed_one(ix, win, seed_len, k, l);
-    // streamed once, read once by the vote kernels: keep it out of the way of the index tables in L2 / MALL
-    __builtin_nontemporal_store((rr > 0 && rr < (uint64_t) thres) ? (k | (rr << 40)) : 0ull, out);
+    const uint32_t np = (uint32_t) (phase_hi - phase_lo + 1);
+    const uint32_t cap_pp = SS_ITEMS / np + 1;                 // survivors of one phase in one workgroup
+    const uint32_t tid = threadIdx.x;
+    if (tid < np) { s_cnt[tid] = 0; s_hits[tid] = 0; }
+    __syncthreads();
+    // iter fastest: neighbouring seeds overlap, so they share their fate (a sequencing error kills ~20 consecutive
+    // seeds, a clean stretch lets all of them run the full backward extension): wavefronts diverge little.
+    // Measured alternatives that lost: q fastest (+26 %), two seeds per lane at once (+26 %), lane refill from a
+    // work chunk (+13 %), packing the survivors of the table lookup into fewer wavefronts (+8 %): the kernel is
+    // bound by the rate of memory requests, not by idle lanes or wavefront slots.
+    const uint32_t len = lens[read];
+    const uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;   // alnmain.c:353 (fenced for len<s)
+    const uint64_t *words = reads2 + read * words_per_read;
+#pragma unroll 1
+    for (uint32_t it = 0; it < SS_ITEMS / 256; ++it) {
+        const uint32_t item = chunk * SS_ITEMS + it * 256 + tid;
+        const uint32_t q = item / np, ph = item % np;
+        if (q >= cap_q) break;
+        const uint64_t j = (uint64_t) (phase_lo + (int) ph) + (uint64_t) q * (uint64_t) P;
+        if (j >= jl) continue;
+        const uint64_t win = read_window(words, (uint32_t) j);
+        uint64_t k, l;
+        const uint64_t rr = seed_one(ix, win, seed_len, k, l);
+        if (rr > 0 && rr < (uint64_t) thres) {
+            const uint32_t slot = atomicAdd(&s_cnt[ph], 1u);
+            atomicAdd(&s_hits[ph], (uint32_t) rr);
+            s_rec[ph * cap_pp + slot] = k | (rr << 40);
+            s_q[ph * cap_pp + slot] = q;
+        }
+    }
+    __syncthreads();
+    if (tid < np) {
+        const uint32_t c = s_cnt[tid];
+        if (c) {
+            const uint64_t id = read * (uint64_t) P + (uint64_t) (phase_lo + (int) tid);
+            s_base[tid] = atomicAdd(&gcnt[id], c);
+            atomicAdd(&ghits[id], s_hits[tid]);
+        }
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < np * cap_pp; e += 256) {
+        const uint32_t ph = e / cap_pp, sl = e - ph * cap_pp;
+        if (sl < s_cnt[ph]) {
+            const uint64_t o = (read * (uint64_t) P + (uint64_t) (phase_lo + (int) ph)) * cap_q + s_base[ph] + sl;
+            rec[o] = s_rec[e];
+            recq[o] = s_q[e];
+        }
+    }
 }
 
 // debug tap: full (j, rr, k, l) per seed of one read, in (iter, q) order
@@ -281,31 +319,31 @@ __global__ __launch_bounds__(256) void seed_search_debug_kernel(LrmIndexView ix,
 
 // ----------------------------------------------------------------------------------------
 // K2 vote.
-// histo_add / histo_find_2_max (histo.c:42-56, 84-96) order entries by insertion; the stable
-// top-2 is "val descending, first-seen ascending".  First-seen order of a bucket is the order of
-// (seed ordinal q, SA offset t) of its first hit = the index h of that hit in the phase's
-// flattened hit list, which is intrinsic to the hit -- so the table can be filled in any order:
-// every slot keeps the count, the low 4 bits of the minimum key and the minimum h.
+// histo_add / histo_find_2_max (histo.c:42-56, 84-96) order entries by insertion; the stable top-2 is "val
+// descending, first-seen ascending".  First-seen order of a bucket is the order of (seed ordinal q, SA offset t)
+// of its first hit, which is intrinsic to the hit -- so the table can be filled in any order: every slot keeps the
+// count, the low 4 bits of the minimum key and the minimum order key (q << tbits) | t.
 //
-// The vote table always lives in LDS.  Items ((read, phase) pairs) are tiered by their hit count
-// H = sum of rr, an upper bound on the distinct buckets:
-//   tier 1   H <= 192         vote_wave: one wavefront per item, 256 slots, 4 items per workgroup; stores H
-//   tier 2a  H <= 384         vote_wave2<512>: one single-wavefront workgroup per item
-//   tier 2b  H <= 768         vote_wave2<1024>
-//   tier 3   any H            vote_block: one 256-thread workgroup per item, 1280 slots, ceil(H/960) passes:
-//                             pass p only admits buckets with hash % passes == p, the per-pass top-2 are
-//                             merged (buckets of different passes are disjoint, so the merge is exact)
-// Every tier is launched over all items and keeps those whose stored H is in its range (one 4-byte read): no
-// work lists, no global atomics.
+// The vote table always lives in LDS.  ONE kernel votes every (read, phase) item; a 256-thread workgroup owns
+// VG consecutive items and routes each by its hit count H (an upper bound on its distinct buckets, left by
+// seed_search next to the survivor list):
+//   H == 0            the zero result
+//   H <= T1_LIMIT     one WAVEFRONT per item (the four wavefronts work on different items), 256-slot table
+//   H >  T1_LIMIT     the whole WORKGROUP on one item after the other, T3_SLOTS-slot table, ceil(H / T3_LIMIT)
+//                     passes: pass p admits only buckets with hash % passes == p and the per-pass top-2 are merged
+//                     (buckets of different passes are disjoint, so the merge is exact)
+// Hits are expanded FLAT: the survivors' hit counts are prefix-summed into LDS, and hit h of the item finds its
+// seed by a binary search over the prefix -- every lane gathers one SA row per step whatever the shape of the
+// item, and all gathers of a step (up to 4 per lane) are in flight before the first vote is cast.  (The first
+// version walked repeat seeds two at a time, one memory latency per pair: an item with 24 repeat seeds took 12
+// dependent round trips, now 1-2.)
 // ----------------------------------------------------------------------------------------
+#define VG 16
 #define T1_SLOTS 256
 #define T1_LIMIT 192
-#define T2A_SLOTS 512        // tier 2a / 2b: per-wavefront tables
-#define T2A_LIMIT 384
-#define T2W_SLOTS 1024
-#define T2W_LIMIT 768
 #define T3_SLOTS 1280
 #define T3_LIMIT 960
+#define T3_CHUNK 512            // survivors per prefix chunk of the workgroup tier (2 per thread)
 #define EMPTY32 0xFFFFFFFFu
 
 struct Cand { uint32_t val; uint32_t first; uint32_t slot; };
@@ -332,10 +370,6 @@ __device__ __forceinline__ void merge_top2(Cand &b1, Cand &b2, const Cand &o1, c
     }
 }
 
-__device__ __forceinline__ uint32_t phase_count(uint32_t jl, uint32_t iter, uint32_t P) {
-    return jl > iter ? (jl - iter + P - 1) / P : 0;
-}
-
 __device__ __forceinline__ uint32_t bucket_hash(uint64_t bucket) {
     return (uint32_t) ((bucket * 0x9E3779B97F4A7C15ull) >> 32);
 }
@@ -346,9 +380,8 @@ struct VoteTable {
     uint32_t slots;
 };
 
-// Returns false only if the table is full (never for tiers 1/2, where H <= 0.75*slots; in the
-// multi-pass tier only under a pathological hash skew) -- the probe loop is bounded so a wave can
-// never spin.
+// Returns false only if the table is full (never in the wavefront tier, where H <= 0.75*slots; in the multi-pass
+// tier only under a pathological hash skew) -- the probe loop is bounded so a wave can never spin.
 __device__ __forceinline__ bool vote_insert(const VoteTable &t, uint64_t key, uint32_t h, uint32_t hash) {
     const uint64_t bucket = key >> 4;                                   // histo.c:26-28
     uint32_t slot = (uint32_t) (((uint64_t) hash * t.slots) >> 32);
@@ -374,157 +407,99 @@ __device__ __forceinline__ void write_phase(LrmPhaseRes *out, const PhaseTop &p)
     *out = res;
 }
 
-// ---- tiers 1 and 2: one wavefront per item ---------------------------------------------------
-// First-seen order key of a hit = (seed ordinal q << tbits) | SA offset t  (t < thres <= 2^tbits),
-// strictly monotone in the reference's (j asc, k asc) insertion order, so no prefix sums are needed.
-// Seeds with a handful of hits are voted by their own lane; a seed with many hits (a repeat) is
-// spread over all 64 lanes.
-#define VOTE_BATCH 8          // records per lane kept in registers: one memory latency per 512 seeds
-
-// Loads the records of seeds [q0, q0 + 64*VOTE_BATCH) of one phase, all loads in flight at once.
-__device__ __forceinline__ void load_records(const uint64_t *__restrict__ r, uint32_t cnt, uint32_t q0, int lane,
-                                             uint64_t (&e)[VOTE_BATCH]) {
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 #pragma unroll
-    for (int u = 0; u < VOTE_BATCH; ++u) {
-        uint32_t q = q0 + (uint32_t) u * 64 + (uint32_t) lane;
-        e[u] = q < cnt ? r[q] : 0ull;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d);
+        if (lane >= d) v += o;
     }
+    return v;
 }
 
-// Votes the hits of 64 seeds (one per lane; e = packed record, q = seed ordinal).  Seeds with a
-// handful of hits are voted by their own lane; a seed with many hits (a repeat) is spread over the
-// 64 lanes of the wavefront.  passes > 1: only buckets with hash % passes == pass are admitted.
-// The SA gathers are the long-latency part, so they are issued in batches before any vote is cast:
-// the <= 4 entries of a small seed together, and the first 64 entries of up to 4 repeat seeds together.
-__device__ __forceinline__ bool vote_admit(const VoteTable &t, uint64_t key, uint32_t order, uint32_t passes,
-                                           uint32_t pass) {
-    uint32_t hash = bucket_hash(key >> 4);
-    if (passes == 1 || hash % passes == pass) return vote_insert(t, key, order, hash);
-    return true;
+// survivor s of the hit h: off[s] <= h < off[s + 1]  (off: exclusive prefix of the survivors' hit counts, strictly
+// increasing because every survivor has at least one hit; cnt >= 1)
+__device__ __forceinline__ uint32_t find_seed(const uint32_t *off, uint32_t cnt, uint32_t h) {
+    uint32_t lo = 0, hi = cnt;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= h) lo = mid; else hi = mid;
+    }
+    return lo;
 }
 
-// Repeat seeds (rr > 4): the hits of one seed are a contiguous run of SA rows, read by the whole wavefront.
+#define VOTE_U 4              // SA gathers in flight per lane
 
-// BIG_GRP seeds at a time, and for each of them the next BIG_U x 64 SA rows: all gathers of a group are issued
-// before its first vote, so a repeat seed with up to 320 hits costs ONE memory latency instead of five.
-#define BIG_GRP 2
-#define BIG_U 5
-__device__ __forceinline__ bool vote_big_seeds(const LrmIndexView &ix, const VoteTable &t, uint32_t rr, uint64_t k,
-                                               uint32_t q0, uint32_t iter, uint32_t P, uint32_t tbits, int lane,
-                                               uint32_t passes, uint32_t pass) {
+// The hits [0, total) of the survivors staged in LDS (off / srec / sq), voted by NT threads (tid of NT).
+template <int NT>
+__device__ __forceinline__ bool vote_hits(const LrmIndexView &ix, const VoteTable &t, const uint32_t *off,
+                                          const uint64_t *srec, const uint32_t *sq, uint32_t cnt, uint32_t total,
+                                          uint32_t iter, uint32_t P, uint32_t tbits, uint32_t tid, uint32_t passes,
+                                          uint32_t pass) {
     bool ok = true;
-    unsigned long long big = __ballot(rr > 4);
-    while (big) {
-        uint32_t rs[BIG_GRP], qs[BIG_GRP];
-        uint64_t ks[BIG_GRP], js[BIG_GRP];
+    for (uint32_t hb = 0; hb < total; hb += NT * VOTE_U) {
+        uint64_t v[VOTE_U];
+        uint32_t ss[VOTE_U], tt[VOTE_U];
 #pragma unroll
-        for (int g = 0; g < BIG_GRP; ++g) {
-            rs[g] = 0; qs[g] = 0; ks[g] = 0; js[g] = 0;
-            if (big) {
-                const int src = __builtin_ctzll(big);
-                big &= big - 1;
-                rs[g] = (uint32_t) __builtin_amdgcn_readlane((int) rr, src);
-                const uint32_t klo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) k, src);
-                const uint32_t khi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (k >> 32), src);
-                ks[g] = ((uint64_t) khi << 32) | klo;
-                qs[g] = q0 + (uint32_t) src;
-                js[g] = (uint64_t) iter + (uint64_t) qs[g] * (uint64_t) P;
+        for (int u = 0; u < VOTE_U; ++u) {
+            const uint32_t h = hb + (uint32_t) u * NT + tid;
+            v[u] = 0; ss[u] = 0; tt[u] = 0;
+            if (h < total) {
+                const uint32_t s = find_seed(off, cnt, h);
+                ss[u] = s;
+                tt[u] = h - off[s];
+                v[u] = sa_locate(ix, (srec[s] & ((1ull << 40) - 1ull)) + tt[u]);
             }
         }
-        uint32_t rmax = rs[0];
 #pragma unroll
-        for (int g = 1; g < BIG_GRP; ++g) rmax = rs[g] > rmax ? rs[g] : rmax;
-        for (uint32_t base = 0; base < rmax; base += 64 * BIG_U) {        // one trip unless thres > 320
-            uint64_t v[BIG_GRP][BIG_U];
-#pragma unroll
-            for (int g = 0; g < BIG_GRP; ++g)
-#pragma unroll
-                for (int u = 0; u < BIG_U; ++u) {
-                    const uint32_t tt = base + (uint32_t) u * 64 + (uint32_t) lane;
-                    v[g][u] = tt < rs[g] ? sa_locate(ix, ks[g] + tt) : 0ull;
-                }
-#pragma unroll
-            for (int g = 0; g < BIG_GRP; ++g)
-#pragma unroll
-                for (int u = 0; u < BIG_U; ++u) {
-                    const uint32_t tt = base + (uint32_t) u * 64 + (uint32_t) lane;
-                    if (tt < rs[g]) ok &= vote_admit(t, v[g][u] - js[g], (qs[g] << tbits) | tt, passes, pass);
-                }
+        for (int u = 0; u < VOTE_U; ++u) {
+            const uint32_t h = hb + (uint32_t) u * NT + tid;
+            if (h < total) {
+                const uint32_t q = sq[ss[u]];
+                const uint64_t key = v[u] - ((uint64_t) iter + (uint64_t) q * (uint64_t) P);   // alnmain.c:363-365 (u64 wrap kept)
+                const uint32_t hash = bucket_hash(key >> 4);
+                if (passes == 1 || hash % passes == pass) ok &= vote_insert(t, key, (q << tbits) | tt[u], hash);
+            }
         }
     }
     return ok;
 }
 
-__device__ __forceinline__ void load_small_hits(const LrmIndexView &ix, uint32_t rr, uint64_t k, uint64_t (&sv)[4]) {
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) sv[tt] = (rr <= 4 && (uint32_t) tt < rr) ? sa_locate(ix, k + (uint32_t) tt) : 0ull;
-}
+// ---- wavefront tier: H <= T1_LIMIT, so at most T1_LIMIT survivors -------------------------------------------
+struct WaveLds {
+    uint64_t bucket[T1_SLOTS];
+    uint64_t srec[T1_LIMIT];
+    uint32_t count[T1_SLOTS], first[T1_SLOTS], minlow[T1_SLOTS];
+    uint32_t off[T1_LIMIT + 4];
+    uint32_t sq[T1_LIMIT];
+};
 
-__device__ __forceinline__ bool vote_small_hits(const VoteTable &t, uint32_t rr, const uint64_t (&sv)[4], uint32_t q,
-                                                uint64_t jq, uint32_t tbits, uint32_t passes, uint32_t pass) {
-    bool ok = true;
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
-        if (rr <= 4 && (uint32_t) tt < rr) ok &= vote_admit(t, sv[tt] - jq, (q << tbits) | (uint32_t) tt, passes, pass);
-    return ok;
-}
-
-__device__ __forceinline__ bool vote_chunk(const LrmIndexView &ix, const VoteTable &t, uint64_t e,
-                                           uint32_t q, uint32_t iter, uint32_t P, uint32_t tbits, int lane,
-                                           uint32_t passes, uint32_t pass) {
-    const uint32_t rr = (uint32_t) (e >> 40);
-    const uint64_t k = e & ((1ull << 40) - 1ull);
-    const uint64_t jq = (uint64_t) iter + (uint64_t) q * (uint64_t) P;      // alnmain.c:363-365 (u64 wrap kept)
-    uint64_t sv[4];
-    load_small_hits(ix, rr, k, sv);
-    bool ok = vote_small_hits(t, rr, sv, q, jq, tbits, passes, pass);
-    ok &= vote_big_seeds(ix, t, rr, k, q - (uint32_t) lane, iter, P, tbits, lane, passes, pass);
-    return ok;
-}
-
-template <int SLOTS>
-__device__ __forceinline__ void vote_item_wave(const LrmIndexView &ix, const uint64_t *__restrict__ r, uint32_t cnt,
-                                               uint32_t iter, uint32_t P, uint32_t H, uint32_t tbits, int lane,
-                                               uint64_t *tb_bucket, uint32_t *tb_count, uint32_t *tb_first,
-                                               uint32_t *tb_minlow, LrmPhaseRes *out,
-                                               uint64_t (&e0)[VOTE_BATCH]) {
-    VoteTable t = {tb_bucket, tb_count, tb_first, tb_minlow, 0};
+__device__ __forceinline__ void vote_item_wave(const LrmIndexView &ix, const uint64_t *__restrict__ rec,
+                                               const uint32_t *__restrict__ recq, uint32_t cnt, uint32_t H,
+                                               uint32_t iter, uint32_t P, uint32_t tbits, int lane, WaveLds &L,
+                                               LrmPhaseRes *out) {
+    VoteTable t = {L.bucket, L.count, L.first, L.minlow, 0};
     {   // clear / scan only as much of the table as this item can fill (<= 75 % load)
-        uint32_t eff = H + H / 3 + 64;
-        t.slots = eff < (uint32_t) SLOTS ? eff : (uint32_t) SLOTS;
+        const uint32_t eff = H + H / 3 + 64;
+        t.slots = eff < (uint32_t) T1_SLOTS ? eff : (uint32_t) T1_SLOTS;
     }
     for (uint32_t s = lane; s < t.slots; s += 64) {
         t.bucket[s] = EMPTY64; t.count[s] = 0; t.first[s] = EMPTY32; t.minlow[s] = EMPTY32;
     }
+    uint32_t run = 0;
+#pragma unroll
+    for (int u = 0; u < (T1_LIMIT + 63) / 64; ++u) {
+        const uint32_t s = (uint32_t) u * 64 + (uint32_t) lane;
+        const uint64_t e = s < cnt ? rec[s] : 0ull;
+        const uint32_t qq = s < cnt ? recq[s] : 0u;
+        const uint32_t rr = (uint32_t) (e >> 40);
+        const uint32_t incl = wave_incl_scan(rr, lane);
+        if (s < cnt) { L.off[s] = run + incl - rr; L.srec[s] = e; L.sq[s] = qq; }
+        run += (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+    }
+    if (lane == 0) L.off[cnt] = run;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-
-    for (uint32_t qb = 0; qb < cnt; qb += 64 * VOTE_BATCH) {
-        uint64_t ev[VOTE_BATCH];
-        if (qb == 0) {
-#pragma unroll
-            for (int u = 0; u < VOTE_BATCH; ++u) ev[u] = e0[u];        // already loaded by the hit count
-        } else {
-            load_records(r, cnt, qb, lane, ev);
-        }
-        uint64_t sv[VOTE_BATCH][4];
-#pragma unroll
-        for (int u = 0; u < VOTE_BATCH; ++u)                 // every small seed's SA entries: one memory latency
-            load_small_hits(ix, (uint32_t) (ev[u] >> 40), ev[u] & ((1ull << 40) - 1ull), sv[u]);
-#pragma unroll
-        for (int u = 0; u < VOTE_BATCH; ++u) {
-            const uint32_t q = qb + (uint32_t) u * 64 + (uint32_t) lane;
-            vote_small_hits(t, (uint32_t) (ev[u] >> 40), sv[u], q, (uint64_t) iter + (uint64_t) q * (uint64_t) P, tbits,
-                            1u, 0u);
-        }
-#pragma unroll
-        for (int u = 0; u < VOTE_BATCH; ++u) {
-            const uint32_t q0 = qb + (uint32_t) u * 64;
-            if (q0 >= cnt) break;
-            vote_big_seeds(ix, t, (uint32_t) (ev[u] >> 40), ev[u] & ((1ull << 40) - 1ull), q0, iter, P, tbits, lane,
-                           1u, 0u);
-        }
-    }
+    vote_hits<64>(ix, t, L.off, L.srec, L.sq, cnt, run, iter, P, tbits, (uint32_t) lane, 1u, 0u);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -545,189 +520,148 @@ __device__ __forceinline__ void vote_item_wave(const LrmIndexView &ix, const uin
         if (b2.val) { p.val2 = b2.val; p.bucket2 = t.bucket[b2.slot]; p.key2 = (p.bucket2 << 4) | t.minlow[b2.slot]; }
         write_phase(out, p);
     }
+    __builtin_amdgcn_wave_barrier();
 }
 
-// hit count of a phase = upper bound on its distinct buckets; the first 512 records stay in e0
-__device__ __forceinline__ uint32_t wave_hit_count(const uint64_t *__restrict__ r, uint32_t cnt, int lane,
-                                                   uint64_t (&e0)[VOTE_BATCH]) {
-    load_records(r, cnt, 0, lane, e0);
-    uint32_t my = 0;
-#pragma unroll
-    for (int u = 0; u < VOTE_BATCH; ++u) my += (uint32_t) (e0[u] >> 40);
-    for (uint32_t q = 64 * VOTE_BATCH + lane; q < cnt; q += 64) my += (uint32_t) (r[q] >> 40);
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) my += __shfl_xor(my, m);
-    return my;
-}
+// ---- workgroup tier -------------------------------------------------------------------------------------------
+struct BlockLds {
+    uint64_t bucket[T3_SLOTS];
+    uint64_t srec[T3_CHUNK];
+    uint32_t count[T3_SLOTS], first[T3_SLOTS], minlow[T3_SLOTS];
+    uint32_t off[T3_CHUNK + 4];
+    uint32_t sq[T3_CHUNK];
+};
+union VoteLds { WaveLds w[4]; BlockLds b; };
 
-// tier 1: grid over every (read, phase) item, 256 slots per wavefront
-__global__ __launch_bounds__(256) void vote_wave_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
-                                                        const uint32_t *__restrict__ lens,
-                                                        const uint8_t *__restrict__ decided, uint64_t n,
-                                                        int seed_len, int phase_lo, int phase_hi, uint32_t cap_q,
-                                                        uint32_t tbits, uint32_t limit,
-                                                        LrmPhaseRes *__restrict__ phase_res,
-                                                        uint32_t *__restrict__ hcount) {
-    __shared__ uint64_t s_bucket[4][T1_SLOTS];
-    __shared__ uint32_t s_count[4][T1_SLOTS], s_first[4][T1_SLOTS], s_minlow[4][T1_SLOTS];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int P = seed_len + 1;
-    const int np = phase_hi - phase_lo + 1;
-    uint64_t item = (uint64_t) blockIdx.x * 4 + wave;
-    if (item >= n * (uint64_t) np) return;
-    uint64_t read = item / (uint64_t) np;
-    int iter = phase_lo + (int) (item % (uint64_t) np);
-    if (decided && decided[read]) return;
-    uint32_t len = lens[read];
-    uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;
-    uint32_t cnt = phase_count(jl, (uint32_t) iter, (uint32_t) P);
-    const uint64_t id = read * (uint64_t) P + (uint64_t) iter;
-    const uint64_t *r = rec + id * cap_q;
-    uint64_t e0[VOTE_BATCH];
-    const uint32_t H = wave_hit_count(r, cnt, lane, e0);
-    // The hit count routes the item: no work lists, no global atomics (a single list-append counter
-    // saturates at ~90 appends/us, which made the appends cost more than the votes).  The larger
-    // tiers are launched over all items and drop the ones that are not theirs after one 4-byte read.
-    if (lane == 0) hcount[id] = H;
-    if (H == 0) {
-        if (lane == 0) { LrmPhaseRes z = {0, 0, 0, 0, 0, 0}; phase_res[id] = z; }
-        return;
+__device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const uint64_t *__restrict__ rec,
+                                                const uint32_t *__restrict__ recq, uint32_t cnt, uint32_t H,
+                                                uint32_t iter, uint32_t P, uint32_t tbits, uint32_t slots, uint32_t limit,
+                                                BlockLds &L, uint32_t *s_wsum, Cand *s_c1, Cand *s_c2, LrmPhaseRes *out,
+                                                uint32_t *err_word) {
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    const int lane = (int) (tid & 63);
+    VoteTable t = {L.bucket, L.count, L.first, L.minlow, slots};
+    const uint32_t passes = (H + limit - 1) / limit;
+    {
+        const uint32_t per_pass = passes > 1 ? limit : H;
+        const uint32_t eff = per_pass + per_pass / 3 + 64;
+        t.slots = eff < slots ? eff : slots;
     }
-    if (H > limit) return;
-    vote_item_wave<T1_SLOTS>(ix, r, cnt, (uint32_t) iter, (uint32_t) P, H, tbits, lane, s_bucket[wave], s_count[wave],
-                             s_first[wave], s_minlow[wave], &phase_res[id], e0);
-}
-
-// tier 2: grid over every item as well, ONE wavefront per workgroup (a wavefront that finds its
-// item in another tier exits and gives its LDS back at once); keeps lim_lo < H <= lim_hi.
-// Two instances: 512 slots (H <= 384) and 1024 slots (H <= 768).
-template <int SLOTS>
-__global__ __launch_bounds__(64) void vote_wave2_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
-                                                        const uint32_t *__restrict__ lens,
-                                                        const uint8_t *__restrict__ decided, uint64_t n,
-                                                        int seed_len, int phase_lo, int phase_hi, uint32_t cap_q,
-                                                        uint32_t tbits, uint32_t lim_lo, uint32_t lim_hi,
-                                                        LrmPhaseRes *__restrict__ phase_res,
-                                                        const uint32_t *__restrict__ hcount) {
-    __shared__ uint64_t tb_bucket[SLOTS];
-    __shared__ uint32_t tb_count[SLOTS], tb_first[SLOTS], tb_minlow[SLOTS];
-    const int lane = threadIdx.x & 63;
-    const int P = seed_len + 1;
-    const int np = phase_hi - phase_lo + 1;
-    const uint64_t item = (uint64_t) blockIdx.x;
-    if (item >= n * (uint64_t) np) return;
-    const uint64_t read = item / (uint64_t) np;
-    const int iter = phase_lo + (int) (item % (uint64_t) np);
-    if (decided && decided[read]) return;
-    const uint64_t id = read * (uint64_t) P + (uint64_t) iter;
-    const uint32_t H = hcount[id];
-    if (H <= lim_lo || H > lim_hi) return;
-    const uint32_t len = lens[read];
-    const uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;
-    const uint32_t cnt = phase_count(jl, (uint32_t) iter, (uint32_t) P);
-    const uint64_t *r = rec + id * cap_q;
-    uint64_t e0[VOTE_BATCH];
-    load_records(r, cnt, 0, lane, e0);
-    vote_item_wave<SLOTS>(ix, r, cnt, (uint32_t) iter, (uint32_t) P, H, tbits, lane, tb_bucket, tb_count, tb_first,
-                          tb_minlow, &phase_res[id], e0);
-}
-
-// ---- tier 3: one 256-thread workgroup per item; a workgroup owns T3_GROUP consecutive items and
-// works on those whose hit count exceeds the wavefront tiers.  The table is shared by the workgroup
-// and an item takes ceil(H / limit) passes over its hits.  Needs the 32-bit (q,t) order key.
-#define T3_GROUP 16
-__global__ __launch_bounds__(256) void vote_block_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
-                                                         const uint32_t *__restrict__ lens,
-                                                         const uint8_t *__restrict__ decided, uint64_t n,
-                                                         int seed_len, int phase_lo, int phase_hi, uint32_t cap_q,
-                                                         LrmPhaseRes *__restrict__ phase_res,
-                                                         const uint32_t *__restrict__ hcount, uint32_t slots,
-                                                         uint32_t limit, uint32_t lim_lo, uint32_t tbits,
-                                                         uint32_t *err_word) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t vsmem[];
-    __shared__ Cand s_c1[4], s_c2[4];
-
-    VoteTable t;
-    t.slots = slots;
-    t.bucket = reinterpret_cast<uint64_t *>(vsmem);
-    t.count = reinterpret_cast<uint32_t *>(vsmem + (size_t) slots * 8);
-    t.first = t.count + slots;
-    t.minlow = t.first + slots;
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int P = seed_len + 1;
-    const int np = phase_hi - phase_lo + 1;
-    const uint64_t n_items = n * (uint64_t) np;
-
-    for (int g = 0; g < T3_GROUP; ++g) {
-        const uint64_t item = (uint64_t) blockIdx.x * T3_GROUP + g;
-        if (item >= n_items) return;
-        const uint64_t read = item / (uint64_t) np;
-        const uint32_t iter = (uint32_t) phase_lo + (uint32_t) (item % (uint64_t) np);
-        if (decided && decided[read]) continue;
-        const uint64_t id = read * (uint64_t) P + (uint64_t) iter;
-        const uint32_t H = hcount[id];
-        if (H <= lim_lo) continue;
-        const uint32_t len = lens[read];
-        const uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;
-        const uint32_t cnt = phase_count(jl, iter, (uint32_t) P);
-        const uint64_t *r = rec + id * cap_q;
-        const uint32_t passes = (H + limit - 1) / limit;
-        {
-            uint32_t per_pass = passes > 1 ? limit : H;
-            uint32_t eff = per_pass + per_pass / 3 + 64;
-            t.slots = eff < slots ? eff : slots;
+    PhaseTop best = {};
+    for (uint32_t pass = 0; pass < passes; ++pass) {
+        for (uint32_t s = tid; s < t.slots; s += 256) {
+            t.bucket[s] = EMPTY64; t.count[s] = 0; t.first[s] = EMPTY32; t.minlow[s] = EMPTY32;
         }
-        PhaseTop best = {};
-        for (uint32_t pass = 0; pass < passes; ++pass) {
-            for (uint32_t s = tid; s < t.slots; s += 256) {
-                t.bucket[s] = EMPTY64; t.count[s] = 0; t.first[s] = EMPTY32; t.minlow[s] = EMPTY32;
-            }
+        bool ok = true;
+        for (uint32_t c0 = 0; c0 < cnt; c0 += T3_CHUNK) {
+            const uint32_t nc = cnt - c0 < (uint32_t) T3_CHUNK ? cnt - c0 : (uint32_t) T3_CHUNK;
+            // two consecutive survivors per thread, one block scan of the per-thread sums
+            const uint32_t s0 = 2 * tid, s1 = s0 + 1;
+            const uint64_t e0 = s0 < nc ? rec[c0 + s0] : 0ull, e1 = s1 < nc ? rec[c0 + s1] : 0ull;
+            const uint32_t q0 = s0 < nc ? recq[c0 + s0] : 0u, q1 = s1 < nc ? recq[c0 + s1] : 0u;
+            const uint32_t r0 = (uint32_t) (e0 >> 40), r1 = (uint32_t) (e1 >> 40);
+            const uint32_t incl = wave_incl_scan(r0 + r1, lane);
+            __syncthreads();                                   // the previous chunk's (or pass's) staging is no longer read
+            if (lane == 63) s_wsum[wave] = incl;
             __syncthreads();
-            bool ok = true;
-            for (uint32_t q0 = 0; q0 < cnt; q0 += 256) {      // each wavefront votes its own 64 seeds
-                const uint32_t qw = q0 + (uint32_t) wave * 64, q = qw + lane;
-                const uint64_t e = q < cnt ? r[q] : 0ull;
-                            ok &= vote_chunk(ix, t, e, q, iter, (uint32_t) P, tbits, lane, passes, pass);
-            }
-            if (!ok) *(volatile uint32_t *) err_word = LRM_ERR_VOTE_OVERFLOW;   // host-coherent, sticky
-            __syncthreads();
-            Cand b1 = {0u, EMPTY32, 0u}, b2 = {0u, EMPTY32, 0u};
-            for (uint32_t s = tid; s < t.slots; s += 256) {
-                Cand c = {t.count[s], t.first[s], s};
-                if (better(c, b1)) { b2 = b1; b1 = c; }
-                else if (better(c, b2)) b2 = c;
-            }
+            uint32_t woff = 0, total = 0;
 #pragma unroll
-            for (int m = 1; m < 64; m <<= 1) {
-                Cand o1 = shfl_xor_cand(b1, m), o2 = shfl_xor_cand(b2, m);
-                merge_top2(b1, b2, o1, o2);
-            }
-            if (lane == 0) { s_c1[wave] = b1; s_c2[wave] = b2; }
+            for (uint32_t w = 0; w < 4; ++w) { const uint32_t x = s_wsum[w]; total += x; if (w < wave) woff += x; }
+            const uint32_t excl = woff + incl - (r0 + r1);
+            if (s0 < nc) { L.off[s0] = excl; L.srec[s0] = e0; L.sq[s0] = q0; }
+            if (s1 < nc) { L.off[s1] = excl + r0; L.srec[s1] = e1; L.sq[s1] = q1; }
+            if (tid == 0) L.off[nc] = total;
             __syncthreads();
-            if (tid == 0) {
-                Cand a1 = s_c1[0], a2 = s_c2[0];
-                for (int w = 1; w < 4; ++w) merge_top2(a1, a2, s_c1[w], s_c2[w]);
-                // merge this pass's top-2 into the running top-2 (disjoint bucket sets)
-                Cand r1 = {best.val1, best.first1, 0u}, r2 = {best.val2, best.first2, 0u};
-                PhaseTop nb = best;
-                Cand cs[2] = {a1, a2};
-                for (int x = 0; x < 2; ++x) {
-                    const Cand &c = cs[x];
-                    if (!c.val) continue;
-                    uint64_t bk = t.bucket[c.slot], ky = (bk << 4) | t.minlow[c.slot];
-                    if (better(c, r1)) {
-                        nb.key2 = nb.key1; nb.bucket2 = nb.bucket1; nb.val2 = nb.val1; nb.first2 = nb.first1; r2 = r1;
-                        nb.key1 = ky; nb.bucket1 = bk; nb.val1 = c.val; nb.first1 = c.first; r1 = c;
-                    } else if (better(c, r2)) {
-                        nb.key2 = ky; nb.bucket2 = bk; nb.val2 = c.val; nb.first2 = c.first; r2 = c;
-                    }
-                }
-                best = nb;
-            }
-            __syncthreads();
+            ok &= vote_hits<256>(ix, t, L.off, L.srec, L.sq, nc, total, iter, P, tbits, tid, passes, pass);
         }
-        if (tid == 0) write_phase(&phase_res[id], best);
+        if (!ok) *(volatile uint32_t *) err_word = LRM_ERR_VOTE_OVERFLOW;   // host-coherent, sticky
+        __syncthreads();
+        Cand b1 = {0u, EMPTY32, 0u}, b2 = {0u, EMPTY32, 0u};
+        for (uint32_t s = tid; s < t.slots; s += 256) {
+            Cand c = {t.count[s], t.first[s], s};
+            if (better(c, b1)) { b2 = b1; b1 = c; }
+            else if (better(c, b2)) b2 = c;
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            Cand o1 = shfl_xor_cand(b1, m), o2 = shfl_xor_cand(b2, m);
+            merge_top2(b1, b2, o1, o2);
+        }
+        if (lane == 0) { s_c1[wave] = b1; s_c2[wave] = b2; }
+        __syncthreads();
+        if (tid == 0) {
+            Cand a1 = s_c1[0], a2 = s_c2[0];
+            for (int w = 1; w < 4; ++w) merge_top2(a1, a2, s_c1[w], s_c2[w]);
+            // merge this pass's top-2 into the running top-2 (disjoint bucket sets)
+            Cand r1 = {best.val1, best.first1, 0u}, r2 = {best.val2, best.first2, 0u};
+            PhaseTop nb = best;
+            Cand cs[2] = {a1, a2};
+            for (int x = 0; x < 2; ++x) {
+                const Cand &c = cs[x];
+                if (!c.val) continue;
+                uint64_t bk = t.bucket[c.slot], ky = (bk << 4) | t.minlow[c.slot];
+                if (better(c, r1)) {
+                    nb.key2 = nb.key1; nb.bucket2 = nb.bucket1; nb.val2 = nb.val1; nb.first2 = nb.first1; r2 = r1;
+                    nb.key1 = ky; nb.bucket1 = bk; nb.val1 = c.val; nb.first1 = c.first; r1 = c;
+                } else if (better(c, r2)) {
+                    nb.key2 = ky; nb.bucket2 = bk; nb.val2 = c.val; nb.first2 = c.first; r2 = c;
+                }
+            }
+            best = nb;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) write_phase(out, best);
+}
+
+__global__ __launch_bounds__(256) void vote_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
+                                                   const uint32_t *__restrict__ recq,
+                                                   const uint32_t *__restrict__ gcnt,
+                                                   const uint32_t *__restrict__ ghits,
+                                                   const uint8_t *__restrict__ decided, uint64_t n, int seed_len,
+                                                   int phase_lo, int phase_hi, uint32_t cap_q, uint32_t tbits,
+                                                   uint32_t slots3, uint32_t limit3,
+                                                   LrmPhaseRes *__restrict__ phase_res, uint32_t *err_word) {
+    __shared__ VoteLds lds;
+    __shared__ uint32_t g_H[VG], g_cnt[VG];
+    __shared__ uint64_t g_id[VG];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ Cand s_c1[4], s_c2[4];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    const int lane = (int) (tid & 63);
+    const uint32_t P = (uint32_t) seed_len + 1;
+    const uint32_t np = (uint32_t) (phase_hi - phase_lo + 1);
+    const uint64_t n_items = n * (uint64_t) np;
+    if (tid < VG) {
+        const uint64_t item = (uint64_t) blockIdx.x * VG + tid;
+        uint32_t H = 0, c = 0;
+        uint64_t id = 0;
+        if (item < n_items) {
+            const uint64_t read = item / np;
+            id = read * (uint64_t) P + (uint64_t) phase_lo + (item % np);
+            if (!(decided && decided[read])) {
+                H = ghits[id];
+                c = gcnt[id];
+                if (H == 0) { LrmPhaseRes z = {0, 0, 0, 0, 0, 0}; phase_res[id] = z; }
+            }
+        }
+        g_H[tid] = H; g_cnt[tid] = c; g_id[tid] = id;
+    }
+    __syncthreads();
+    for (uint32_t g = wave; g < VG; g += 4) {                 // wavefront tier: four items at a time
+        const uint32_t H = g_H[g];
+        if (H == 0 || H > (uint32_t) T1_LIMIT) continue;
+        const uint64_t id = g_id[g];
+        vote_item_wave(ix, rec + id * cap_q, recq + id * cap_q, g_cnt[g], H, (uint32_t) (id % P), P, tbits, lane,
+                       lds.w[wave], &phase_res[id]);
+    }
+    __syncthreads();
+    for (uint32_t g = 0; g < VG; ++g) {                       // workgroup tier: one item after the other
+        const uint32_t H = g_H[g];
+        if (H <= (uint32_t) T1_LIMIT) continue;
+        const uint64_t id = g_id[g];
+        vote_item_block(ix, rec + id * cap_q, recq + id * cap_q, g_cnt[g], H, (uint32_t) (id % P), P, tbits, slots3,
+                        limit3, lds.b, s_wsum, s_c1, s_c2, &phase_res[id], err_word);
         __syncthreads();
     }
 }
@@ -817,6 +751,7 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
 
     HIPCHK(hipMemsetAsync(ws->d_counters, 0, sizeof(LrmDevCounters), stream));
     HIPCHK(hipMemsetAsync(ws->d_hcount, 0, n * (uint64_t) P * 4, stream));
+    HIPCHK(hipMemsetAsync(ws->d_cnt, 0, n * (uint64_t) P * 4, stream));
     ws->n_last = n;
     {
         uint64_t bpr = wpr * 8;
@@ -828,61 +763,42 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
                            d_lens, (uint8_t *) ws->d_reads2, bpr, cpr, n);
         lrm_time_end(ws, stream);
     }
+    uint32_t tbits = 1;
+    while ((1u << tbits) < thres && tbits < 31) tbits++;
+    if (((uint64_t) cap_q << tbits) > 0xffffffffull) {
+        lrm_set_error("read too long for the vote order key: cap_q %u << %u bits exceeds 32 bits", cap_q, tbits);
+        return -1;
+    }
+    uint32_t t3_limit = T3_LIMIT, t3_slots = T3_SLOTS;
+    if (const char *e = getenv("LRM_T3_LIMIT")) {        // test knobs: a pass limit above the table size and a
+        const long long v = atoll(e);                     // small table force overflows of the multi-pass tier
+        if (v >= 1) t3_limit = (uint32_t) v;
+    }
+    if (const char *e = getenv("LRM_T3_SLOTS")) {
+        const long long v = atoll(e);
+        if (v >= 8 && v <= T3_SLOTS) t3_slots = (uint32_t) v;
+    }
     for (int round = 0; round < 2; ++round) {
         int lo = round == 0 ? 0 : 1;
         int hi = round == 0 ? 0 : P - 1;
         if (lo > hi) break;
         int np = hi - lo + 1;
         const uint8_t *dec = round == 0 ? nullptr : ws->d_decided;
-        uint32_t bpr = (uint32_t) (((uint64_t) np * cap_q + 255) / 256);
+        uint32_t bpr = (uint32_t) (((uint64_t) np * cap_q + SS_ITEMS - 1) / SS_ITEMS);
         uint64_t blocks = n * bpr;
         if (blocks > 0x7fffffffull) { lrm_set_error("seed_search grid too large: split the batch"); return -1; }
         lrm_time_begin(ws, LRM_K_SEED_SEARCH, stream);
         hipLaunchKernelGGL(seed_search_kernel, dim3((uint32_t) blocks), dim3(256), 0, stream, idx->view,
                            ws->d_reads2, wpr, d_lens, dec, n, (int) seed_len, thres, lo, hi, cap_q, bpr,
-                           ws->d_rec);
+                           ws->d_rec, ws->d_recq, ws->d_cnt, ws->d_hcount);
         lrm_time_end(ws, stream);
-        // tiered vote: every tier is launched over all items and keeps the ones in its hit-count range
         uint64_t items = n * (uint64_t) np;
-        uint64_t vblocks = (items + 3) / 4;
+        uint64_t vblocks = (items + VG - 1) / VG;
         if (vblocks > 0x7fffffffull) { lrm_set_error("vote grid too large: split the batch"); return -1; }
-        uint32_t tbits = 1;
-        while ((1u << tbits) < thres && tbits < 31) tbits++;
-        if (((uint64_t) cap_q << tbits) > 0xffffffffull) {
-            lrm_set_error("read too long for the vote order key: cap_q %u << %u bits exceeds 32 bits", cap_q, tbits);
-            return -1;
-        }
         lrm_time_begin(ws, LRM_K_VOTE, stream);
-        hipLaunchKernelGGL(vote_wave_kernel, dim3((uint32_t) vblocks), dim3(256), 0, stream, idx->view, ws->d_rec,
-                           d_lens, dec, n, (int) seed_len, lo, hi, cap_q, tbits, (uint32_t) T1_LIMIT, ws->d_phase,
-                           ws->d_hcount);
-        lrm_time_end(ws, stream);
-        lrm_time_begin(ws, LRM_K_VOTE_WAVE2, stream);
-        {
-            size_t sh3 = (size_t) T3_SLOTS * 20;
-            uint32_t t3_limit = T3_LIMIT, t3_slots = T3_SLOTS;
-            if (const char *e = getenv("LRM_T3_LIMIT")) {        // test knobs: a pass limit above the table size and a
-                const long long v = atoll(e);                     // small table force overflows of the multi-pass tier
-                if (v >= 1) t3_limit = (uint32_t) v;
-            }
-            if (const char *e = getenv("LRM_T3_SLOTS")) {
-                const long long v = atoll(e);
-                if (v >= 8 && v <= T3_SLOTS) t3_slots = (uint32_t) v;
-            }
-            if (items > 0x7fffffffull) { lrm_set_error("vote grid too large: split the batch"); return -1; }
-            hipLaunchKernelGGL(vote_wave2_kernel<T2A_SLOTS>, dim3((uint32_t) items), dim3(64), 0, stream, idx->view,
-                               ws->d_rec, d_lens, dec, n, (int) seed_len, lo, hi, cap_q, tbits, (uint32_t) T1_LIMIT,
-                               (uint32_t) T2A_LIMIT, ws->d_phase, ws->d_hcount);
-            hipLaunchKernelGGL(vote_wave2_kernel<T2W_SLOTS>, dim3((uint32_t) items), dim3(64), 0, stream, idx->view,
-                               ws->d_rec, d_lens, dec, n, (int) seed_len, lo, hi, cap_q, tbits, (uint32_t) T2A_LIMIT,
-                               (uint32_t) T2W_LIMIT, ws->d_phase, ws->d_hcount);
-            lrm_time_end(ws, stream);
-            lrm_time_begin(ws, LRM_K_VOTE_BLOCK, stream);
-            uint64_t b3 = (items + T3_GROUP - 1) / T3_GROUP;
-            hipLaunchKernelGGL(vote_block_kernel, dim3((uint32_t) b3), dim3(256), sh3, stream, idx->view, ws->d_rec,
-                               d_lens, dec, n, (int) seed_len, lo, hi, cap_q, ws->d_phase, ws->d_hcount,
-                               t3_slots, t3_limit, (uint32_t) T2W_LIMIT, tbits, ws->d_err);
-        }
+        hipLaunchKernelGGL(vote_kernel, dim3((uint32_t) vblocks), dim3(256), 0, stream, idx->view, ws->d_rec, ws->d_recq,
+                           ws->d_cnt, ws->d_hcount, dec, n, (int) seed_len, lo, hi, cap_q, tbits, t3_slots, t3_limit,
+                           ws->d_phase, ws->d_err);
         lrm_time_end(ws, stream);
         lrm_time_begin(ws, LRM_K_DECIDE, stream);
         hipLaunchKernelGGL(decide_kernel, dim3((uint32_t) ((n + 255) / 256)), dim3(256), 0, stream, ws->d_phase,

@@ -117,6 +117,16 @@ class HostIndex:
     def blob_bytes(self):
         return int(lib.lrm_index_blob_bytes(self.length, self.hlen, self.mta_len))
 
+    def pack_device(self, device=0):
+        """The image packed straight into a torch uint8 CUDA tensor (no host copy): broadcast it, then adopt."""
+        import torch
+        n = self.blob_bytes()
+        t = torch.empty(n, dtype=torch.uint8, device=torch.device("cuda", device))
+        check(lib.lrm_index_pack_device(C.byref(self.h.fmi), C.byref(self.h.lch), C.byref(self.h.sa), self.h.content,
+                                        self.h.con_len, self.h.mta, self.h.mta_len, t.data_ptr(), n, device),
+              "lrm_index_pack_device")
+        return t
+
     def pack_blob(self, out=None):
         """Serialise to the device image in host memory (numpy uint8)."""
         n = self.blob_bytes()

@@ -17,7 +17,7 @@ assert ENTRY_DT.itemsize == 24 and META_DT.itemsize == 24
 DEFAULT_SEED_LEN = 20      # alnmain.c:577-580
 DEFAULT_THRES = 300
 DEFAULT_GACT = (320, 120, 128)
-N_KERNELS = 11             # LRM_N_KERNELS in include/lrm_accel.h
+N_KERNELS = 9              # LRM_N_KERNELS in include/lrm_accel.h
 
 
 def seed_batch(index, reads, lens, seed_len=DEFAULT_SEED_LEN, thres=DEFAULT_THRES):
