@@ -100,6 +100,10 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
+    # OpenMP (index builder, staging copies, the CPU oracle) must not spawn one thread per hardware thread of the
+    # host when the job only owns a share of it (cgroup quota): oversubscribed threads are throttled
+    os.environ.setdefault("OMP_NUM_THREADS", str(usable_cpus()))
+
     import torch
     import torch.distributed as tdist
     from longreadmapper_amd import dist, index, mapper, synth

@@ -234,10 +234,9 @@ extern "C" int lrm_accaln(const char *genome, const char *reads_path, const char
         std::vector<lrm_seq_meta> meta((size_t) n);
         const uint64_t sstride = (uint64_t) b.max_len * 2 > 0 ? (uint64_t) b.max_len * 2 : 1;   // alnmain.c:316-320
         std::vector<uint8_t> store((size_t) n * sstride);
-        rc = lrm_seed_batch(gpu, b.seqs, b.stride, b.lens, (uint64_t) n, p, best.data());
-        if (rc == 0)
-            rc = lrm_extend_batch(gpu, b.seqs, b.stride, b.lens, (uint64_t) n, best.data(), gp, cig.data(), store.data(),
-                                  sstride, score.data(), meta.data(), meta_r.data());
+        // PART 1 + PART 2 in one device pass (the reads cross the link once)
+        rc = lrm_map_batch(gpu, b.seqs, b.stride, b.lens, (uint64_t) n, p, gp, best.data(), cig.data(), store.data(),
+                           sstride, score.data(), meta.data(), meta_r.data());
         if (rc == 0) {
             uint64_t tl = 0;
             char *txt = lrm_sam_format(&b, hi.mta, hi.mta_len, cig.data(), score.data(), meta.data(), meta_r.data(),

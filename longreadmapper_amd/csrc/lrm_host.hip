@@ -6,12 +6,16 @@
 // thread per replica, every replica writes its slice of the caller's arrays in place -- SURVEY 8(b)/(e); the
 // host loop this replaces is alnmain.c:302-330).
 //
-// A batch goes through a device in sub-batches over THREE sets of device mirrors: while the kernels of
-// sub-batch k run on the compute stream, the issuing thread uploads sub-batch k+1 and a second host thread
-// downloads the results of sub-batch k-1, so both directions of the link and the GPU are busy at once.
-// Caller buffers that are pinned (lrm_host_alloc / lrm_host_register) are handed to the DMA engines directly;
-// pageable ones (what alnmain.c mallocs) are staged chunk-wise through pinned memory, the host half of every
-// chunk being a multi-threaded memcpy that overlaps the DMA of the previous chunk.
+// A batch goes through a device in sub-batches over THREE sets of device mirrors, each with its own compute
+// stream and workspace: while the kernels of sub-batch k run, the issuing thread uploads sub-batch k+1 (whose
+// seed kernels then overlap the extension of k: one is bound by memory latency, the other by VALU issue) and a
+// second host thread downloads the results of sub-batch k-1, so both directions of the link and the GPU are busy
+// at once.  Results leave the device DENSE: a pack kernel gathers the used part of every CIGAR row and the
+// reverse-complemented reads (the only rows of reads_buf that changed) into one contiguous buffer, which crosses
+// the link at the full DMA rate (a strided hipMemcpy2D of the same rows measured 6 GB/s against 57 GB/s flat) and
+// is scattered into the caller's rows by a multi-threaded memcpy.  Reads that are pinned (lrm_host_alloc /
+// lrm_host_register) are uploaded by the DMA engines directly; pageable ones (what alnmain.c mallocs) are staged
+// chunk-wise through pinned memory, the host half of every chunk overlapping the DMA of the previous chunk.
 // No CPU fallback: without a HIP device every entry point fails.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -45,16 +49,16 @@ struct DevSlot {
 constexpr uint64_t STAGE_CHUNK = 32ull << 20;
 constexpr int N_SETS = 3;
 constexpr int COPY_THREADS = 8;       // enough to outrun the link; a library must not fan out over every core of its host
-struct DevSet { DevSlot reads, lens, best, store, nops, score, meta, mr; };
+struct DevSet { DevSlot reads, lens, best, store, nops, score, meta, mr, dense, offs; };
 
 }  // namespace
 
 struct LrmHostCtx {
     std::mutex mu;                       // one host-buffer call at a time per replica (re-entrant per handle otherwise)
-    lrm_workspace *ws = nullptr;
+    lrm_workspace *ws[N_SETS] = {};      // one workspace and one compute stream per set of mirrors
     DevSet set[N_SETS];
     void *pin_up[2] = {nullptr, nullptr}, *pin_dn[2] = {nullptr, nullptr};
-    hipStream_t up = nullptr, down = nullptr, comp = nullptr;
+    hipStream_t up = nullptr, down = nullptr, comp[N_SETS] = {};
     hipEvent_t ev_pin_up[2] = {nullptr, nullptr}, ev_pin_dn[2] = {nullptr, nullptr};
     hipEvent_t ev_up[N_SETS] = {}, ev_done[N_SETS] = {};
     bool pin_up_used[2] = {false, false};
@@ -76,8 +80,9 @@ int ctx_init(LrmHostCtx &c) {
         if (hipEventCreateWithFlags(&c.ev_up[s], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c.ev_done[s], hipEventDisableTiming) != hipSuccess) { lrm_set_error("event creation failed"); return -1; }
     if (hipStreamCreateWithFlags(&c.up, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c.down, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c.comp, hipStreamNonBlocking) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
+        hipStreamCreateWithFlags(&c.down, hipStreamNonBlocking) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
+    for (int s = 0; s < N_SETS; ++s)
+        if (hipStreamCreateWithFlags(&c.comp[s], hipStreamNonBlocking) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
     c.ready = true;
     return 0;
 }
@@ -91,11 +96,14 @@ void par_memcpy(void *dst, const void *src, uint64_t bytes) {
     }
 }
 
-// pinned (hipHostMalloc / hipHostRegister) memory can be handed to the DMA engines as it is
-bool is_pinned(const void *p) {
+// pinned (hipHostMalloc / hipHostRegister) memory can be handed to the DMA engines as it is, and kernels can
+// write it through its device alias (*dev_alias)
+bool is_pinned(const void *p, void **dev_alias = nullptr) {
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void) hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeHost;
+    if (a.type != hipMemoryTypeHost) return false;
+    if (dev_alias) *dev_alias = a.devicePointer;
+    return true;
 }
 
 // host -> device on the upload stream; returns when the last byte has been handed to the DMA engine (not when
@@ -115,39 +123,76 @@ int h2d(LrmHostCtx &c, void *d_dst, const void *h_src, uint64_t bytes, bool pinn
     return 0;
 }
 
-// device -> host on the download stream, `rows` rows of `width` bytes (device pitch spitch, host pitch dpitch);
-// rows == 1 is a flat copy.  Synchronous for the caller (the download thread).
-int d2h(LrmHostCtx &c, void *h_dst, uint64_t dpitch, const void *d_src, uint64_t spitch, uint64_t width, uint64_t rows,
-        bool pinned) {
-    if (width == 0 || rows == 0) return 0;
-    const bool flat = rows == 1;
-    if (pinned) {
-        if (flat) HIPCHK(hipMemcpyAsync(h_dst, d_src, width, hipMemcpyDeviceToHost, c.down));
-        else HIPCHK(hipMemcpy2DAsync(h_dst, dpitch, d_src, spitch, width, rows, hipMemcpyDeviceToHost, c.down));
-        HIPCHK(hipStreamSynchronize(c.down));
-        return 0;
+// pack kernel: row i of a pitched device array (len[i] bytes; 0 = skip) -> dense[off[i] ..), 16 bytes per lane.
+// Rows start at any byte (the hardware takes the unaligned dwords); dense offsets are 16-byte aligned.
+__global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t *__restrict__ src, uint64_t pitch,
+                                                        const uint32_t *__restrict__ len, const uint64_t *__restrict__ off,
+                                                        uint8_t *__restrict__ dense, uint64_t rows) {
+    const uint64_t row = blockIdx.x;
+    if (row >= rows) return;
+    const uint32_t l = len[row];
+    const uint8_t *s = src + row * pitch;
+    uint8_t *d = dense + off[row];
+    for (uint32_t o = (blockIdx.y * 256 + threadIdx.x) * 16; o < l; o += gridDim.y * 256 * 16) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (o + 16 <= l) __builtin_memcpy(w, s + o, 16);
+        else for (uint32_t e = 0; o + e < l; ++e) w[e >> 2] |= (uint32_t) s[o + e] << (8 * (e & 3));
+        *reinterpret_cast<uint4 *>(d + o) = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    const uint64_t unit = flat ? STAGE_CHUNK : STAGE_CHUNK / width;
-    if (unit == 0) { lrm_set_error("row wider than a staging chunk"); return -1; }
-    const uint64_t total = flat ? width : rows;                      // bytes (flat) or rows
+}
+
+// rows of a pitched device array -> rows of another pitched array (len[i] bytes of row i; 0 = skip).  The
+// destination may be the device alias of PINNED HOST memory: the stores then cross the link as posted writes,
+// 1 KiB per wavefront instruction, and the caller's rows are filled with no staging copy and no host work.
+__global__ __launch_bounds__(256) void copy_rows_kernel(const uint8_t *__restrict__ src, uint64_t spitch,
+                                                        uint8_t *__restrict__ dst, uint64_t dpitch,
+                                                        const uint32_t *__restrict__ len, uint64_t rows) {
+    const uint64_t row = blockIdx.x;
+    if (row >= rows) return;
+    const uint32_t l = len[row];
+    const uint8_t *s = src + row * spitch;
+    uint8_t *d = dst + row * dpitch;
+    const uint32_t head = (uint32_t) ((16u - ((uintptr_t) d & 15u)) & 15u);         // bytes up to the first aligned 16
+    if (blockIdx.y == 0) for (uint32_t o = threadIdx.x; o < head && o < l; o += 256) d[o] = s[o];
+    for (uint32_t o = head + (blockIdx.y * 256 + threadIdx.x) * 16; o < l; o += gridDim.y * 256 * 16) {
+        if (o + 16 <= l) {
+            uint32_t w[4];
+            __builtin_memcpy(w, s + o, 16);
+            *reinterpret_cast<uint4 *>(d + o) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (uint32_t e = 0; o + e < l; ++e) d[o + e] = s[o + e];
+        }
+    }
+}
+
+// dense device buffer -> rows of a pitched host array: contiguous DMA through the pinned chunks, every chunk
+// scattered into the caller's rows by COPY_THREADS threads while the next one flies.
+// off[i] (16-byte aligned, ascending) / len[i]: position and length of row i in the dense buffer; rows are
+// numbered from 0 and land at h_dst + i*pitch.
+int d2h_dense(LrmHostCtx &c, uint8_t *h_dst, uint64_t pitch, const uint8_t *d_dense, uint64_t total, const uint64_t *off,
+              const uint32_t *len, uint64_t rows) {
+    if (total == 0) return 0;
     uint64_t k = 0, o = 0, prev_o = 0, prev_l = 0;
+    uint64_t row_lo = 0;                                              // first row that may still have bytes at or after prev_o
     while (true) {
         const int b = (int) (k & 1);
-        const uint64_t l = o < total ? (total - o < unit ? total - o : unit) : 0;
+        const uint64_t l = o < total ? (total - o < STAGE_CHUNK ? total - o : STAGE_CHUNK) : 0;
         if (l) {
-            if (flat) HIPCHK(hipMemcpyAsync(c.pin_dn[b], (const char *) d_src + o, l, hipMemcpyDeviceToHost, c.down));
-            else HIPCHK(hipMemcpy2DAsync(c.pin_dn[b], width, (const char *) d_src + o * spitch, spitch, width, l,
-                                         hipMemcpyDeviceToHost, c.down));
+            HIPCHK(hipMemcpyAsync(c.pin_dn[b], d_dense + o, l, hipMemcpyDeviceToHost, c.down));
             HIPCHK(hipEventRecord(c.ev_pin_dn[b], c.down));
         }
-        if (prev_l) {                                                 // unpack the previous chunk while this one flies
+        if (prev_l) {                                                 // scatter the previous chunk while this one flies
             const int pb = (int) ((k - 1) & 1);
             HIPCHK(hipEventSynchronize(c.ev_pin_dn[pb]));
-            if (flat) par_memcpy((char *) h_dst + prev_o, c.pin_dn[pb], prev_l);
-            else {
+            const uint8_t *chunk = (const uint8_t *) c.pin_dn[pb];
+            const uint64_t c0 = prev_o, c1 = prev_o + prev_l;
+            while (row_lo < rows && off[row_lo] + len[row_lo] <= c0) ++row_lo;
+            uint64_t row_hi = row_lo;
+            while (row_hi < rows && off[row_hi] < c1) ++row_hi;
 #pragma omp parallel for schedule(static) num_threads(COPY_THREADS)
-                for (uint64_t r = 0; r < prev_l; ++r)
-                    memcpy((char *) h_dst + (prev_o + r) * dpitch, (const char *) c.pin_dn[pb] + r * width, width);
+            for (uint64_t r = row_lo; r < row_hi; ++r) {
+                const uint64_t a = off[r] > c0 ? off[r] : c0, e = off[r] + len[r] < c1 ? off[r] + len[r] : c1;
+                if (e > a) memcpy(h_dst + r * pitch + (a - off[r]), chunk + (a - c0), e - a);
             }
         }
         if (l == 0) break;
@@ -199,13 +244,13 @@ struct MapJob {
     }
 };
 
-int get_ws(LrmHostCtx &c, lrm_index *idx, uint64_t n, uint32_t max_len, uint32_t seed_len, uint32_t thres, bool exact) {
-    lrm_workspace *ws = c.ws;
+int get_ws(LrmHostCtx &c, int s, lrm_index *idx, uint64_t n, uint32_t max_len, uint32_t seed_len, uint32_t thres, bool exact) {
+    lrm_workspace *ws = c.ws[s];
     if (ws && n <= ws->n_max && max_len <= ws->max_len && (!exact || (seed_len == ws->seed_len && thres <= ws->thres))) return 0;
     if (ws && !exact) { seed_len = ws->seed_len; thres = ws->thres; }     // extend only: keep the seed shape of the cached one
-    if (ws) { lrm_workspace_free(ws); c.ws = nullptr; }
+    if (ws) { lrm_workspace_free(ws); c.ws[s] = nullptr; }
     if (lrm_workspace_create(&ws, idx, n, max_len, seed_len, thres)) return -1;
-    c.ws = ws;
+    c.ws[s] = ws;
     return 0;
 }
 
@@ -227,10 +272,10 @@ struct Pipe {
 struct SubBatch { uint64_t off, m; };
 
 // download of sub-batch k (runs on the download thread once ev_done[k % N_SETS] has fired)
-int collect(LrmHostCtx &c, const MapJob &j, const SubBatch &sb, int s, uint64_t dstride, bool pin_reads, bool pin_store) {
+int collect(LrmHostCtx &c, const MapJob &j, const SubBatch &sb, int s, uint64_t dstride) {
     DevSet &d = c.set[s];
     HIPCHK(hipEventSynchronize(c.ev_done[s]));
-    if (lrm_ws_take_error(c.ws)) return -2;                        // raised by this or an earlier sub-batch: never lost
+    if (lrm_ws_take_error(c.ws[s])) return -2;                     // raised by this or an earlier sub-batch: never lost
     const uint64_t m = sb.m, o = sb.off;
     if (j.mode & DO_SEED) HIPCHK(hipMemcpyAsync(j.best_out + o, d.best.p, m * sizeof(lrm_entry), hipMemcpyDeviceToHost, c.down));
     if (!(j.mode & DO_EXTEND)) { HIPCHK(hipStreamSynchronize(c.down)); return 0; }
@@ -240,12 +285,59 @@ int collect(LrmHostCtx &c, const MapJob &j, const SubBatch &sb, int s, uint64_t 
     HIPCHK(hipMemcpyAsync(j.meta + o, d.meta.p, m * sizeof(lrm_seq_meta), hipMemcpyDeviceToHost, c.down));
     HIPCHK(hipMemcpyAsync(j.meta_r + o, d.mr.p, m * 4, hipMemcpyDeviceToHost, c.down));
     HIPCHK(hipStreamSynchronize(c.down));
-    if (d2h(c, j.reads + o * j.stride, 0, d.reads.p, 0, m * j.stride, 1, pin_reads)) return -1;     // rev-comped reads travel back (alnmain.c:437)
-    int32_t mx = 0;                                                  // only the columns some read uses cross the link
-    for (uint64_t i = 0; i < m; ++i) mx = nops[i] > mx ? nops[i] : mx;
-    uint64_t width = ((uint64_t) mx + 63) & ~63ull;
-    if (width > j.store_stride) width = j.store_stride;
-    if (d2h(c, j.store_mem + o * j.store_stride, j.store_stride, d.store.p, dstride, width, m, pin_store)) return -1;
+    // dense layout: the used part of every CIGAR row, then the reads that were reverse-complemented in place
+    // (alnmain.c:437; the other rows of reads_buf did not change)
+    std::vector<uint64_t> off(2 * m);
+    std::vector<uint32_t> len(2 * m);
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < m; ++i) {
+        const uint64_t cap = j.store_stride;
+        len[i] = nops[i] > 0 ? (uint32_t) ((uint64_t) nops[i] < cap ? (uint64_t) nops[i] : cap) : 0u;
+        off[i] = total;
+        total += ((uint64_t) len[i] + 15) & ~15ull;
+    }
+    const uint64_t total_ops = total;
+    for (uint64_t i = 0; i < m; ++i) {
+        const bool rev = j.meta_r[o + i] != 0 && j.meta[o + i].strand == 1;
+        len[m + i] = rev ? j.lens[o + i] : 0u;
+        off[m + i] = total;
+        total += ((uint64_t) len[m + i] + 15) & ~15ull;
+    }
+    void *store_alias = nullptr, *reads_alias = nullptr;
+    const bool direct = getenv("LRM_HOST_NO_DIRECT") == nullptr &&
+                        is_pinned(j.store_mem + o * j.store_stride, &store_alias) && store_alias &&
+                        is_pinned(j.reads + o * j.stride, &reads_alias) && reads_alias;
+    if (total && direct) {
+        // pinned caller buffers: the device writes the rows straight into them (no dense staging, no host copy)
+        if (d.offs.ensure(2 * m * 12)) { lrm_set_error("device allocation failed"); return -1; }
+        uint32_t *d_len = (uint32_t *) ((uint8_t *) d.offs.p + 2 * m * 8);
+        HIPCHK(hipMemcpyAsync(d_len, len.data(), 2 * m * 4, hipMemcpyHostToDevice, c.down));
+        const uint32_t gy_ops = (uint32_t) ((j.store_stride + 4095) / 4096), gy_rd = (uint32_t) ((j.stride + 4095) / 4096);
+        hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t) m, gy_ops ? gy_ops : 1), dim3(256), 0, c.down, (const uint8_t *) d.store.p,
+                           dstride, (uint8_t *) store_alias, j.store_stride, d_len, m);
+        hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t) m, gy_rd ? gy_rd : 1), dim3(256), 0, c.down, (const uint8_t *) d.reads.p,
+                           j.stride, (uint8_t *) reads_alias, j.stride, d_len + m, m);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c.down));
+    } else if (total) {
+        if (d.dense.ensure(total) || d.offs.ensure(2 * m * 12)) { lrm_set_error("device allocation failed"); return -1; }
+        uint64_t *d_off = (uint64_t *) d.offs.p;
+        uint32_t *d_len = (uint32_t *) ((uint8_t *) d.offs.p + 2 * m * 8);
+        HIPCHK(hipMemcpyAsync(d_off, off.data(), 2 * m * 8, hipMemcpyHostToDevice, c.down));
+        HIPCHK(hipMemcpyAsync(d_len, len.data(), 2 * m * 4, hipMemcpyHostToDevice, c.down));
+        const uint32_t gy_ops = (uint32_t) ((j.store_stride + 4095) / 4096), gy_rd = (uint32_t) ((j.stride + 4095) / 4096);
+        hipLaunchKernelGGL(pack_rows_kernel, dim3((uint32_t) m, gy_ops ? gy_ops : 1), dim3(256), 0, c.down, (const uint8_t *) d.store.p,
+                           dstride, d_len, d_off, (uint8_t *) d.dense.p, m);
+        hipLaunchKernelGGL(pack_rows_kernel, dim3((uint32_t) m, gy_rd ? gy_rd : 1), dim3(256), 0, c.down, (const uint8_t *) d.reads.p,
+                           j.stride, d_len + m, d_off + m, (uint8_t *) d.dense.p, m);
+        HIPCHK(hipGetLastError());
+        if (d2h_dense(c, j.store_mem + o * j.store_stride, j.store_stride, (const uint8_t *) d.dense.p, total_ops, off.data(),
+                      len.data(), m)) return -1;
+        // the reads part: offsets relative to its own start
+        for (uint64_t i = 0; i < m; ++i) off[m + i] -= total_ops;
+        if (d2h_dense(c, (uint8_t *) j.reads + o * j.stride, j.stride, (const uint8_t *) d.dense.p + total_ops, total - total_ops,
+                      off.data() + m, len.data() + m, m)) return -1;
+    }
     for (uint64_t i = 0; i < m; ++i) {                               // alnmain.c:322-325, mutils.c:99-104
         j.cig[o + i].cigar = j.store_mem + (o + i) * j.store_stride;
         j.cig[o + i].n_cigar_op = nops[i];
@@ -257,12 +349,14 @@ int collect(LrmHostCtx &c, const MapJob &j, const SubBatch &sb, int s, uint64_t 
 // one device pass over a slice of the job: the three-stage pipeline
 int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) {
     const uint64_t n = j.n, nsub = pipe_subs(n), sub = (n + nsub - 1) / nsub;
-    if (get_ws(c, idx, sub, max_len, j.p.seed_len, j.p.thres, (j.mode & DO_SEED) != 0)) return -1;
-    lrm_workspace *ws = c.ws;
     const uint64_t dstride = (j.store_stride + 3) & ~3ull;           // the bit-sliced kernel stores CIGAR bytes four at a time
-    const bool pin_reads = is_pinned(j.reads), pin_store = (j.mode & DO_EXTEND) && is_pinned(j.store_mem);
+    const bool pin_reads = is_pinned(j.reads);
     std::vector<SubBatch> subs;
     for (uint64_t off = 0; off < n; off += sub) subs.push_back({off, n - off < sub ? n - off : sub});
+    if (subs.size() > 0x7fffffffull || sub > 0x7fffffffull) { lrm_set_error("batch too large"); return -1; }
+    const int nsets = subs.size() < (size_t) N_SETS ? (int) subs.size() : N_SETS;
+    for (int s = 0; s < nsets; ++s)
+        if (get_ws(c, s, idx, sub, max_len, j.p.seed_len, j.p.thres, (j.mode & DO_SEED) != 0)) return -1;
 
     Pipe pipe;
     const int device = idx->device;
@@ -274,7 +368,7 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
                 pipe.cv.wait(g, [&] { return pipe.issued > k || pipe.stop || pipe.rc; });
                 if (pipe.rc || pipe.issued <= k) return;
             }
-            const int rc = collect(c, j, subs[k], (int) (k % N_SETS), dstride, pin_reads, pin_store);
+            const int rc = collect(c, j, subs[k], (int) (k % N_SETS), dstride);
             if (rc) { pipe.fail(rc); return; }
             { std::lock_guard<std::mutex> g(pipe.m); pipe.collected = k + 1; }
             pipe.cv.notify_all();
@@ -291,6 +385,8 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
             if (pipe.rc) break;
         }
         DevSet &d = c.set[s];
+        lrm_workspace *ws = c.ws[s];
+        hipStream_t comp = c.comp[s];
         auto issue = [&]() -> int {
             if (d.reads.ensure(m * j.stride) || d.lens.ensure(m * 4) || d.best.ensure(m * sizeof(lrm_entry))) { lrm_set_error("device allocation failed"); return -1; }
             if ((j.mode & DO_EXTEND) && (d.store.ensure(m * dstride) || d.nops.ensure(m * 4) || d.score.ensure(m * 4) ||
@@ -299,14 +395,14 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
             HIPCHK(hipMemcpyAsync(d.lens.p, j.lens + off, m * 4, hipMemcpyHostToDevice, c.up));
             if (!(j.mode & DO_SEED)) HIPCHK(hipMemcpyAsync(d.best.p, j.best_in + off, m * sizeof(lrm_entry), hipMemcpyHostToDevice, c.up));
             HIPCHK(hipEventRecord(c.ev_up[s], c.up));
-            HIPCHK(hipStreamWaitEvent(c.comp, c.ev_up[s], 0));
+            HIPCHK(hipStreamWaitEvent(comp, c.ev_up[s], 0));
             if ((j.mode & DO_SEED) && lrm_launch_seed(idx, ws, (const char *) d.reads.p, j.stride, (const uint32_t *) d.lens.p, m, max_len,
-                                                      j.p.seed_len, j.p.thres, (lrm_entry *) d.best.p, c.comp)) return -1;
+                                                      j.p.seed_len, j.p.thres, (lrm_entry *) d.best.p, comp)) return -1;
             if ((j.mode & DO_EXTEND) && lrm_launch_extend(idx, ws, (char *) d.reads.p, j.stride, (const uint32_t *) d.lens.p, m, max_len,
                                                           (const lrm_entry *) d.best.p, j.gp, (uint8_t *) d.store.p, dstride,
                                                           (int32_t *) d.nops.p, (int32_t *) d.score.p, (lrm_seq_meta *) d.meta.p,
-                                                          (int32_t *) d.mr.p, c.comp)) return -1;
-            HIPCHK(hipEventRecord(c.ev_done[s], c.comp));
+                                                          (int32_t *) d.mr.p, comp)) return -1;
+            HIPCHK(hipEventRecord(c.ev_done[s], comp));
             return 0;
         };
         rc = issue();
@@ -318,7 +414,9 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
     pipe.cv.notify_all();
     downloader.join();
     if (pipe.rc) {
-        (void) hipStreamSynchronize(c.comp); (void) hipStreamSynchronize(c.up); (void) hipStreamSynchronize(c.down);
+        for (int s = 0; s < N_SETS; ++s) (void) hipStreamSynchronize(c.comp[s]);
+        (void) hipStreamSynchronize(c.up); (void) hipStreamSynchronize(c.down);
+        for (int s = 0; s < N_SETS; ++s) if (c.ws[s] && c.ws[s]->h_err) *c.ws[s]->h_err = 0;   // reported now: do not fail the next call
         lrm_set_error("%s", pipe.err);
         return pipe.rc;
     }
@@ -390,18 +488,20 @@ void lrm_host_ctx_free(lrm_index *idx) {
     if (!c) return;
     idx->host = nullptr;
     if (c->ready) {
-        (void) hipStreamSynchronize(c->comp); (void) hipStreamSynchronize(c->up); (void) hipStreamSynchronize(c->down);
+        for (int s = 0; s < N_SETS; ++s) (void) hipStreamSynchronize(c->comp[s]);
+        (void) hipStreamSynchronize(c->up); (void) hipStreamSynchronize(c->down);
         for (int b = 0; b < 2; ++b) {
             (void) hipHostFree(c->pin_up[b]); (void) hipHostFree(c->pin_dn[b]);
             (void) hipEventDestroy(c->ev_pin_up[b]); (void) hipEventDestroy(c->ev_pin_dn[b]);
         }
         for (int s = 0; s < N_SETS; ++s) { (void) hipEventDestroy(c->ev_up[s]); (void) hipEventDestroy(c->ev_done[s]); }
-        (void) hipStreamDestroy(c->up); (void) hipStreamDestroy(c->down); (void) hipStreamDestroy(c->comp);
+        (void) hipStreamDestroy(c->up); (void) hipStreamDestroy(c->down);
+        for (int s = 0; s < N_SETS; ++s) (void) hipStreamDestroy(c->comp[s]);
     }
-    if (c->ws) lrm_workspace_free(c->ws);
+    for (int s = 0; s < N_SETS; ++s) if (c->ws[s]) lrm_workspace_free(c->ws[s]);
     for (auto &d : c->set) {
         d.reads.release(); d.lens.release(); d.best.release(); d.store.release();
-        d.nops.release(); d.score.release(); d.meta.release(); d.mr.release();
+        d.nops.release(); d.score.release(); d.meta.release(); d.mr.release(); d.dense.release(); d.offs.release();
     }
     delete c;
 }
@@ -446,13 +546,13 @@ extern "C" int lrm_map_batch(lrm_index *idx, char *reads_buf, uint64_t stride, c
 // directly, no staging copy.  lrm_host_register pins memory the caller already owns (malloc'd at alnmain.c:297-320).
 extern "C" void *lrm_host_alloc(uint64_t bytes) {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void) hipGetLastError(); lrm_set_error("hipHostMalloc of %llu bytes failed", (unsigned long long) bytes); return nullptr; }
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void) hipGetLastError(); lrm_set_error("hipHostMalloc of %llu bytes failed", (unsigned long long) bytes); return nullptr; }
     return p;
 }
 extern "C" void lrm_host_free(void *p) { if (p) (void) hipHostFree(p); }
 extern "C" int lrm_host_register(void *p, uint64_t bytes) {
     if (!p || !bytes) { lrm_set_error("bad argument"); return -1; }
-    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterPortable));
+    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
     return 0;
 }
 extern "C" int lrm_host_unregister(void *p) {

@@ -163,6 +163,76 @@ __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t wi
     return k > l ? 0 : l - k + 1;
 }
 
+// NS seeds per lane searched TOGETHER: the table lookups of all NS seeds are issued before the first is used and
+// every backward step issues the rank gathers of all live seeds before consuming them, so a lane keeps up to NS
+// independent requests in flight instead of one (the kernel is bound by memory latency x resident wavefronts).
+// Same results as NS calls of seed_one; rr[u] = 0 for seeds with act[u] == false.
+template <int NS>
+__device__ __forceinline__ void seed_multi(const LrmIndexView &ix, const uint64_t (&win)[NS], const bool (&act)[NS],
+                                           int seed_len, uint64_t (&k)[NS], uint64_t (&rr)[NS]) {
+    uint64_t l[NS];
+    int left[NS];
+    bool live[NS];
+    const bool use_long = ix.lcl && seed_len >= ix.hl;
+    const int left_long = seed_len - ix.hl, left_ref = seed_len - ix.hlen;
+    uint64_t e[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {                        // all first-level lookups in flight
+        e[u] = 0;
+        if (act[u]) {
+            if (use_long) e[u] = ix.lcl[(win[u] >> (2 * left_long)) & ((1ull << (2 * ix.hl)) - 1ull)];
+            else if (left_ref >= 0) e[u] = ix.lc[(win[u] >> (2 * left_ref)) & ((1ull << (2 * ix.hlen)) - 1ull)];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        k[u] = 0; l[u] = 0; left[u] = 0; live[u] = false; rr[u] = 0;
+        if (!act[u]) continue;
+        if (use_long && (e[u] >> 40) != 0xFFFFFFull) {
+            if (e[u] != 0) { k[u] = e[u] & ((1ull << 40) - 1ull); l[u] = k[u] + (e[u] >> 40) - 1; left[u] = left_long; live[u] = true; }
+        } else if (left_ref >= 0) {
+            // (after a long-table marker the reference's table is read here: rare, intervals >= 2^24-1 rows)
+            lc_lookup(ix, (win[u] >> (2 * left_ref)) & ((1ull << (2 * ix.hlen)) - 1ull), k[u], l[u]);
+            left[u] = left_ref;
+            live[u] = !(k[u] == 0 && l[u] == 0);
+        } else {
+            k[u] = 1; l[u] = ix.length - 1; left[u] = seed_len; live[u] = true;      // seed shorter than hlen (lchash.c:97-99)
+        }
+    }
+    int steps = 0;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) steps = live[u] && left[u] > steps ? left[u] : steps;
+    for (int s = 0; s < steps; ++s) {
+        ulonglong2 ea[NS], eb[NS];
+        uint32_t c[NS];
+        bool go[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {                    // the rank gathers of every live seed in flight
+            go[u] = live[u] && s < left[u];
+            c[u] = 0; ea[u] = make_ulonglong2(0, 0); eb[u] = ea[u];
+            if (go[u]) {
+                c[u] = (uint32_t) (win[u] >> (2 * (left[u] - 1 - s))) & 3u;
+                const uint64_t la = k[u] - 1, lb = l[u];
+                eb[u] = *reinterpret_cast<const ulonglong2 *>(&ix.occ[lb >> 6].sym[c[u]]);
+                ea[u] = eb[u];
+                if ((la >> 6) != (lb >> 6)) ea[u] = *reinterpret_cast<const ulonglong2 *>(&ix.occ[la >> 6].sym[c[u]]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            if (!go[u]) continue;
+            const uint32_t qa = (uint32_t) (k[u] - 1) & 63u, qb = (uint32_t) l[u] & 63u;
+            const uint64_t ra = ea[u].x + (uint64_t) __popcll(ea[u].y & (qa == 63u ? ~0ull : ((2ull << qa) - 1ull)));
+            const uint64_t rb = eb[u].x + (uint64_t) __popcll(eb[u].y & (qb == 63u ? ~0ull : ((2ull << qb) - 1ull)));
+            k[u] = ix.c4[c[u]] + ra + 1;
+            l[u] = ix.c4[c[u]] + rb;
+            if (k[u] > l[u]) live[u] = false;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) rr[u] = (live[u] && k[u] <= l[u]) ? l[u] - k[u] + 1 : 0;
+}
+
 // long table: one lane per hl-mer; the 4^(hl-hlen) extensions of one hlen-mer are contiguous
 __global__ __launch_bounds__(256) void lcl_build_kernel(LrmIndexView ix, int hl, uint64_t *__restrict__ out,
                                                         uint64_t code0) {
@@ -232,6 +302,7 @@ __device__ __forceinline__ uint64_t read_window(const uint64_t *__restrict__ wor
 // (q << tbits) | t, is a property of the hit.
 // ----------------------------------------------------------------------------------------
 #define SS_ITEMS 1024
+template <int MULTI>         // 0: one seed after the other; 2 / 4: that many of the lane's four seeds searched together (seed_multi)
 __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const uint64_t *__restrict__ reads2,
                                                           uint64_t words_per_read,
                                                           const uint32_t *__restrict__ lens,
@@ -261,21 +332,49 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
     const uint32_t len = lens[read];
     const uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;   // alnmain.c:353 (fenced for len<s)
     const uint64_t *words = reads2 + read * words_per_read;
+    if (MULTI) {
+        constexpr int NS = MULTI > 0 ? MULTI : 1;
 #pragma unroll 1
-    for (uint32_t it = 0; it < SS_ITEMS / 256; ++it) {
-        const uint32_t item = chunk * SS_ITEMS + it * 256 + tid;
-        const uint32_t q = item / np, ph = item % np;
-        if (q >= cap_q) break;
-        const uint64_t j = (uint64_t) (phase_lo + (int) ph) + (uint64_t) q * (uint64_t) P;
-        if (j >= jl) continue;
-        const uint64_t win = read_window(words, (uint32_t) j);
-        uint64_t k, l;
-        const uint64_t rr = seed_one(ix, win, seed_len, k, l);
-        if (rr > 0 && rr < (uint64_t) thres) {
-            const uint32_t slot = atomicAdd(&s_cnt[ph], 1u);
-            atomicAdd(&s_hits[ph], (uint32_t) rr);
-            s_rec[ph * cap_pp + slot] = k | (rr << 40);
-            s_q[ph * cap_pp + slot] = q;
+      for (int grp = 0; grp < SS_ITEMS / 256 / NS; ++grp) {
+        uint64_t win[NS], k[NS], rr[NS];
+        uint32_t qs[NS], phs[NS];
+        bool act[NS];
+#pragma unroll
+        for (int it = 0; it < NS; ++it) {
+            const uint32_t item = chunk * SS_ITEMS + (uint32_t) (grp * NS + it) * 256 + tid;
+            qs[it] = item / np; phs[it] = item % np;
+            const uint64_t j = (uint64_t) (phase_lo + (int) phs[it]) + (uint64_t) qs[it] * (uint64_t) P;
+            act[it] = qs[it] < cap_q && j < jl;
+            win[it] = act[it] ? read_window(words, (uint32_t) j) : 0ull;
+        }
+        seed_multi<NS>(ix, win, act, seed_len, k, rr);
+#pragma unroll
+        for (int it = 0; it < NS; ++it) {
+            if (rr[it] > 0 && rr[it] < (uint64_t) thres) {
+                const uint32_t slot = atomicAdd(&s_cnt[phs[it]], 1u);
+                atomicAdd(&s_hits[phs[it]], (uint32_t) rr[it]);
+                s_rec[phs[it] * cap_pp + slot] = k[it] | (rr[it] << 40);
+                s_q[phs[it] * cap_pp + slot] = qs[it];
+            }
+        }
+      }
+    } else {
+#pragma unroll 1
+        for (uint32_t it = 0; it < SS_ITEMS / 256; ++it) {
+            const uint32_t item = chunk * SS_ITEMS + it * 256 + tid;
+            const uint32_t q = item / np, ph = item % np;
+            if (q >= cap_q) break;
+            const uint64_t j = (uint64_t) (phase_lo + (int) ph) + (uint64_t) q * (uint64_t) P;
+            if (j >= jl) continue;
+            const uint64_t win = read_window(words, (uint32_t) j);
+            uint64_t k, l;
+            const uint64_t rr = seed_one(ix, win, seed_len, k, l);
+            if (rr > 0 && rr < (uint64_t) thres) {
+                const uint32_t slot = atomicAdd(&s_cnt[ph], 1u);
+                atomicAdd(&s_hits[ph], (uint32_t) rr);
+                s_rec[ph * cap_pp + slot] = k | (rr << 40);
+                s_q[ph * cap_pp + slot] = q;
+            }
         }
     }
     __syncthreads();
@@ -338,37 +437,14 @@ __global__ __launch_bounds__(256) void seed_search_debug_kernel(LrmIndexView ix,
 // version walked repeat seeds two at a time, one memory latency per pair: an item with 24 repeat seeds took 12
 // dependent round trips, now 1-2.)
 // ----------------------------------------------------------------------------------------
-#define VG 16
+#define VG 16                // items per workgroup (default; LRM_VOTE_VG)
+#define VG_MAX 64
 #define T1_SLOTS 256
 #define T1_LIMIT 192
 #define T3_SLOTS 1280
 #define T3_LIMIT 960
 #define T3_CHUNK 512            // survivors per prefix chunk of the workgroup tier (2 per thread)
 #define EMPTY32 0xFFFFFFFFu
-
-struct Cand { uint32_t val; uint32_t first; uint32_t slot; };
-
-__device__ __forceinline__ bool better(const Cand &a, const Cand &b) {
-    return a.val > b.val || (a.val == b.val && a.first < b.first);
-}
-
-__device__ __forceinline__ Cand shfl_xor_cand(const Cand &c, int m) {
-    Cand o;
-    o.val = __shfl_xor(c.val, m);
-    o.first = __shfl_xor(c.first, m);
-    o.slot = __shfl_xor(c.slot, m);
-    return o;
-}
-
-__device__ __forceinline__ void merge_top2(Cand &b1, Cand &b2, const Cand &o1, const Cand &o2) {
-    if (better(o1, b1)) {
-        Cand s = better(o2, b1) ? o2 : b1;
-        b1 = o1;
-        b2 = s;
-    } else {
-        if (better(o1, b2)) b2 = o1;
-    }
-}
 
 __device__ __forceinline__ uint32_t bucket_hash(uint64_t bucket) {
     return (uint32_t) ((bucket * 0x9E3779B97F4A7C15ull) >> 32);
@@ -407,13 +483,60 @@ __device__ __forceinline__ void write_phase(LrmPhaseRes *out, const PhaseTop &p)
     *out = res;
 }
 
+// inclusive prefix sum over the 64 lanes on the DPP network: four row shifts inside the rows of 16, then the
+// row totals are broadcast to the following rows (row_bcast:15 / row_bcast:31) -- six v_add_u32_dpp, no LDS
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+    (void) lane;
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// Top-2 of a vote table, "count descending, first-seen ascending" (histo.c:84-96 with the insertion order carried
+// by the order key): one u64 per slot, count << 32 | ~first, is unique among the filled slots (every hit has its own
+// order key), so the stable top-2 is the two largest keys.  Every lane scans its slots, then two max-reductions.
+struct Top2 { uint64_t k1, k2; uint32_t s1, s2; };
+
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(v, d);
-        if (lane >= d) v += o;
+    for (int m = 1; m < 64; m <<= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t) v, m), hi = __shfl_xor((uint32_t) (v >> 32), m);
+        const uint64_t o = ((uint64_t) hi << 32) | lo;
+        v = o > v ? o : v;
     }
     return v;
+}
+
+template <int NT>
+__device__ __forceinline__ Top2 table_top2(const VoteTable &t, uint32_t tid) {
+    uint64_t k1 = 0, k2 = 0;
+    uint32_t s1 = 0, s2 = 0;
+    for (uint32_t s = tid; s < t.slots; s += NT) {
+        const uint64_t k = ((uint64_t) t.count[s] << 32) | (uint64_t) (0xFFFFFFFFu - t.first[s]);
+        if (k > k1) { k2 = k1; s2 = s1; k1 = k; s1 = s; }
+        else if (k > k2) { k2 = k; s2 = s; }
+    }
+    // wave-level: the largest key, then the largest of what is left
+    const uint64_t m1 = wave_max_u64(k1);
+    const bool win = k1 == m1 && (m1 >> 32) != 0;
+    const uint64_t m2 = wave_max_u64(win ? k2 : k1);
+    Top2 r;
+    r.k1 = (m1 >> 32) ? m1 : 0; r.k2 = (m2 >> 32) ? m2 : 0; r.s1 = 0; r.s2 = 0;
+    if (r.k1) {
+        const unsigned long long b = __ballot(k1 == m1);
+        r.s1 = (uint32_t) __builtin_amdgcn_readlane((int) s1, (int) __builtin_ctzll(b));
+    }
+    if (r.k2) {
+        const bool has = (win ? k2 : k1) == m2;
+        const unsigned long long b = __ballot(has);
+        const int src = (int) __builtin_ctzll(b);
+        r.s2 = (uint32_t) __builtin_amdgcn_readlane((int) (win ? s2 : s1), src);
+    }
+    return r;
 }
 
 // survivor s of the hit h: off[s] <= h < off[s + 1]  (off: exclusive prefix of the survivors' hit counts, strictly
@@ -427,10 +550,9 @@ __device__ __forceinline__ uint32_t find_seed(const uint32_t *off, uint32_t cnt,
     return lo;
 }
 
-#define VOTE_U 4              // SA gathers in flight per lane
 
 // The hits [0, total) of the survivors staged in LDS (off / srec / sq), voted by NT threads (tid of NT).
-template <int NT>
+template <int NT, int VOTE_U>               // VOTE_U: SA gathers in flight per lane
 __device__ __forceinline__ bool vote_hits(const LrmIndexView &ix, const VoteTable &t, const uint32_t *off,
                                           const uint64_t *srec, const uint32_t *sq, uint32_t cnt, uint32_t total,
                                           uint32_t iter, uint32_t P, uint32_t tbits, uint32_t tid, uint32_t passes,
@@ -473,6 +595,7 @@ struct WaveLds {
     uint32_t sq[T1_LIMIT];
 };
 
+template <int VOTE_U>
 __device__ __forceinline__ void vote_item_wave(const LrmIndexView &ix, const uint64_t *__restrict__ rec,
                                                const uint32_t *__restrict__ recq, uint32_t cnt, uint32_t H,
                                                uint32_t iter, uint32_t P, uint32_t tbits, int lane, WaveLds &L,
@@ -499,25 +622,15 @@ __device__ __forceinline__ void vote_item_wave(const LrmIndexView &ix, const uin
     if (lane == 0) L.off[cnt] = run;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    vote_hits<64>(ix, t, L.off, L.srec, L.sq, cnt, run, iter, P, tbits, (uint32_t) lane, 1u, 0u);
+    vote_hits<64, VOTE_U>(ix, t, L.off, L.srec, L.sq, cnt, run, iter, P, tbits, (uint32_t) lane, 1u, 0u);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    Cand b1 = {0u, EMPTY32, 0u}, b2 = {0u, EMPTY32, 0u};
-    for (uint32_t s = lane; s < t.slots; s += 64) {
-        Cand c = {t.count[s], t.first[s], s};
-        if (better(c, b1)) { b2 = b1; b1 = c; }
-        else if (better(c, b2)) b2 = c;
-    }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        Cand o1 = shfl_xor_cand(b1, m), o2 = shfl_xor_cand(b2, m);
-        merge_top2(b1, b2, o1, o2);
-    }
+    const Top2 w = table_top2<64>(t, (uint32_t) lane);
     if (lane == 0) {
         PhaseTop p = {};
-        if (b1.val) { p.val1 = b1.val; p.bucket1 = t.bucket[b1.slot]; p.key1 = (p.bucket1 << 4) | t.minlow[b1.slot]; }
-        if (b2.val) { p.val2 = b2.val; p.bucket2 = t.bucket[b2.slot]; p.key2 = (p.bucket2 << 4) | t.minlow[b2.slot]; }
+        if (w.k1) { p.val1 = (uint32_t) (w.k1 >> 32); p.bucket1 = t.bucket[w.s1]; p.key1 = (p.bucket1 << 4) | t.minlow[w.s1]; }
+        if (w.k2) { p.val2 = (uint32_t) (w.k2 >> 32); p.bucket2 = t.bucket[w.s2]; p.key2 = (p.bucket2 << 4) | t.minlow[w.s2]; }
         write_phase(out, p);
     }
     __builtin_amdgcn_wave_barrier();
@@ -533,10 +646,11 @@ struct BlockLds {
 };
 union VoteLds { WaveLds w[4]; BlockLds b; };
 
+template <int VOTE_U>
 __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const uint64_t *__restrict__ rec,
                                                 const uint32_t *__restrict__ recq, uint32_t cnt, uint32_t H,
                                                 uint32_t iter, uint32_t P, uint32_t tbits, uint32_t slots, uint32_t limit,
-                                                BlockLds &L, uint32_t *s_wsum, Cand *s_c1, Cand *s_c2, LrmPhaseRes *out,
+                                                BlockLds &L, uint32_t *s_wsum, Top2 *s_top, LrmPhaseRes *out,
                                                 uint32_t *err_word) {
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     const int lane = (int) (tid & 63);
@@ -572,39 +686,40 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
             if (s1 < nc) { L.off[s1] = excl + r0; L.srec[s1] = e1; L.sq[s1] = q1; }
             if (tid == 0) L.off[nc] = total;
             __syncthreads();
-            ok &= vote_hits<256>(ix, t, L.off, L.srec, L.sq, nc, total, iter, P, tbits, tid, passes, pass);
+            ok &= vote_hits<256, VOTE_U>(ix, t, L.off, L.srec, L.sq, nc, total, iter, P, tbits, tid, passes, pass);
         }
         if (!ok) *(volatile uint32_t *) err_word = LRM_ERR_VOTE_OVERFLOW;   // host-coherent, sticky
         __syncthreads();
-        Cand b1 = {0u, EMPTY32, 0u}, b2 = {0u, EMPTY32, 0u};
-        for (uint32_t s = tid; s < t.slots; s += 256) {
-            Cand c = {t.count[s], t.first[s], s};
-            if (better(c, b1)) { b2 = b1; b1 = c; }
-            else if (better(c, b2)) b2 = c;
-        }
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            Cand o1 = shfl_xor_cand(b1, m), o2 = shfl_xor_cand(b2, m);
-            merge_top2(b1, b2, o1, o2);
-        }
-        if (lane == 0) { s_c1[wave] = b1; s_c2[wave] = b2; }
+        const Top2 w = table_top2<256>(t, tid);                       // this wavefront's share of the table
+        if (lane == 0) s_top[wave] = w;
         __syncthreads();
         if (tid == 0) {
-            Cand a1 = s_c1[0], a2 = s_c2[0];
-            for (int w = 1; w < 4; ++w) merge_top2(a1, a2, s_c1[w], s_c2[w]);
-            // merge this pass's top-2 into the running top-2 (disjoint bucket sets)
-            Cand r1 = {best.val1, best.first1, 0u}, r2 = {best.val2, best.first2, 0u};
+            // the pass's top-2 = the two largest of the four wavefronts' pairs; merged into the running top-2 of
+            // the earlier passes (disjoint bucket sets).  Keys compare as (count, first-seen) pairs.
+            uint64_t ck[2] = {0, 0};
+            uint32_t cslot[2] = {0, 0};
+            for (int x = 0; x < 4; ++x) {
+                const Top2 c = s_top[x];
+                const uint64_t ks[2] = {c.k1, c.k2};
+                const uint32_t ss[2] = {c.s1, c.s2};
+                for (int y = 0; y < 2; ++y) {
+                    if (ks[y] > ck[0]) { ck[1] = ck[0]; cslot[1] = cslot[0]; ck[0] = ks[y]; cslot[0] = ss[y]; }
+                    else if (ks[y] > ck[1]) { ck[1] = ks[y]; cslot[1] = ss[y]; }
+                }
+            }
+            uint64_t r1 = best.val1 ? ((uint64_t) best.val1 << 32) | (0xFFFFFFFFu - best.first1) : 0;
+            uint64_t r2 = best.val2 ? ((uint64_t) best.val2 << 32) | (0xFFFFFFFFu - best.first2) : 0;
             PhaseTop nb = best;
-            Cand cs[2] = {a1, a2};
             for (int x = 0; x < 2; ++x) {
-                const Cand &c = cs[x];
-                if (!c.val) continue;
-                uint64_t bk = t.bucket[c.slot], ky = (bk << 4) | t.minlow[c.slot];
-                if (better(c, r1)) {
+                const uint64_t c = ck[x];
+                if (!c) continue;
+                const uint32_t cv = (uint32_t) (c >> 32), cf = 0xFFFFFFFFu - (uint32_t) c;
+                const uint64_t bk = t.bucket[cslot[x]], ky = (bk << 4) | t.minlow[cslot[x]];
+                if (c > r1) {
                     nb.key2 = nb.key1; nb.bucket2 = nb.bucket1; nb.val2 = nb.val1; nb.first2 = nb.first1; r2 = r1;
-                    nb.key1 = ky; nb.bucket1 = bk; nb.val1 = c.val; nb.first1 = c.first; r1 = c;
-                } else if (better(c, r2)) {
-                    nb.key2 = ky; nb.bucket2 = bk; nb.val2 = c.val; nb.first2 = c.first; r2 = c;
+                    nb.key1 = ky; nb.bucket1 = bk; nb.val1 = cv; nb.first1 = cf; r1 = c;
+                } else if (c > r2) {
+                    nb.key2 = ky; nb.bucket2 = bk; nb.val2 = cv; nb.first2 = cf; r2 = c;
                 }
             }
             best = nb;
@@ -614,26 +729,27 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
     if (tid == 0) write_phase(out, best);
 }
 
+template <int VOTE_U>
 __global__ __launch_bounds__(256) void vote_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
                                                    const uint32_t *__restrict__ recq,
                                                    const uint32_t *__restrict__ gcnt,
                                                    const uint32_t *__restrict__ ghits,
                                                    const uint8_t *__restrict__ decided, uint64_t n, int seed_len,
                                                    int phase_lo, int phase_hi, uint32_t cap_q, uint32_t tbits,
-                                                   uint32_t slots3, uint32_t limit3,
+                                                   uint32_t slots3, uint32_t limit3, uint32_t vg, uint32_t limit1,
                                                    LrmPhaseRes *__restrict__ phase_res, uint32_t *err_word) {
     __shared__ VoteLds lds;
-    __shared__ uint32_t g_H[VG], g_cnt[VG];
-    __shared__ uint64_t g_id[VG];
+    __shared__ uint32_t g_H[VG_MAX], g_cnt[VG_MAX];
+    __shared__ uint64_t g_id[VG_MAX];
     __shared__ uint32_t s_wsum[4];
-    __shared__ Cand s_c1[4], s_c2[4];
+    __shared__ Top2 s_top[4];
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     const int lane = (int) (tid & 63);
     const uint32_t P = (uint32_t) seed_len + 1;
     const uint32_t np = (uint32_t) (phase_hi - phase_lo + 1);
     const uint64_t n_items = n * (uint64_t) np;
-    if (tid < VG) {
-        const uint64_t item = (uint64_t) blockIdx.x * VG + tid;
+    if (tid < vg) {
+        const uint64_t item = (uint64_t) blockIdx.x * vg + tid;
         uint32_t H = 0, c = 0;
         uint64_t id = 0;
         if (item < n_items) {
@@ -648,20 +764,20 @@ __global__ __launch_bounds__(256) void vote_kernel(LrmIndexView ix, const uint64
         g_H[tid] = H; g_cnt[tid] = c; g_id[tid] = id;
     }
     __syncthreads();
-    for (uint32_t g = wave; g < VG; g += 4) {                 // wavefront tier: four items at a time
+    for (uint32_t g = wave; g < vg; g += 4) {                 // wavefront tier: four items at a time
         const uint32_t H = g_H[g];
-        if (H == 0 || H > (uint32_t) T1_LIMIT) continue;
+        if (H == 0 || H > limit1) continue;
         const uint64_t id = g_id[g];
-        vote_item_wave(ix, rec + id * cap_q, recq + id * cap_q, g_cnt[g], H, (uint32_t) (id % P), P, tbits, lane,
+        vote_item_wave<VOTE_U>(ix, rec + id * cap_q, recq + id * cap_q, g_cnt[g], H, (uint32_t) (id % P), P, tbits, lane,
                        lds.w[wave], &phase_res[id]);
     }
     __syncthreads();
-    for (uint32_t g = 0; g < VG; ++g) {                       // workgroup tier: one item after the other
+    for (uint32_t g = 0; g < vg; ++g) {                       // workgroup tier: one item after the other
         const uint32_t H = g_H[g];
-        if (H <= (uint32_t) T1_LIMIT) continue;
+        if (H <= limit1) continue;
         const uint64_t id = g_id[g];
-        vote_item_block(ix, rec + id * cap_q, recq + id * cap_q, g_cnt[g], H, (uint32_t) (id % P), P, tbits, slots3,
-                        limit3, lds.b, s_wsum, s_c1, s_c2, &phase_res[id], err_word);
+        vote_item_block<VOTE_U>(ix, rec + id * cap_q, recq + id * cap_q, g_cnt[g], H, (uint32_t) (id % P), P, tbits, slots3,
+                        limit3, lds.b, s_wsum, s_top, &phase_res[id], err_word);
         __syncthreads();
     }
 }
@@ -778,6 +894,14 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
         const long long v = atoll(e);
         if (v >= 8 && v <= T3_SLOTS) t3_slots = (uint32_t) v;
     }
+    // tuning knobs (measured defaults; tools/seed_probe.py sweeps them)
+    uint32_t vg = VG, t1_limit = T1_LIMIT;
+    int vote_u = 4;
+    if (const char *e = getenv("LRM_VOTE_VG")) { const int v = atoi(e); if (v >= 1 && v <= VG_MAX) vg = (uint32_t) v; }
+    if (const char *e = getenv("LRM_VOTE_T1")) { const int v = atoi(e); if (v >= 0 && v <= T1_LIMIT) t1_limit = (uint32_t) v; }
+    if (const char *e = getenv("LRM_VOTE_U")) vote_u = atoi(e);
+    int ss_multi = 4;
+    if (const char *e = getenv("LRM_SS_MULTI")) ss_multi = atoi(e);
     for (int round = 0; round < 2; ++round) {
         int lo = round == 0 ? 0 : 1;
         int hi = round == 0 ? 0 : P - 1;
@@ -788,17 +912,19 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
         uint64_t blocks = n * bpr;
         if (blocks > 0x7fffffffull) { lrm_set_error("seed_search grid too large: split the batch"); return -1; }
         lrm_time_begin(ws, LRM_K_SEED_SEARCH, stream);
-        hipLaunchKernelGGL(seed_search_kernel, dim3((uint32_t) blocks), dim3(256), 0, stream, idx->view,
+        auto sk = ss_multi == 4 ? seed_search_kernel<4> : ss_multi == 2 ? seed_search_kernel<2> : seed_search_kernel<0>;
+        hipLaunchKernelGGL(sk, dim3((uint32_t) blocks), dim3(256), 0, stream, idx->view,
                            ws->d_reads2, wpr, d_lens, dec, n, (int) seed_len, thres, lo, hi, cap_q, bpr,
                            ws->d_rec, ws->d_recq, ws->d_cnt, ws->d_hcount);
         lrm_time_end(ws, stream);
         uint64_t items = n * (uint64_t) np;
-        uint64_t vblocks = (items + VG - 1) / VG;
+        uint64_t vblocks = (items + vg - 1) / vg;
         if (vblocks > 0x7fffffffull) { lrm_set_error("vote grid too large: split the batch"); return -1; }
         lrm_time_begin(ws, LRM_K_VOTE, stream);
-        hipLaunchKernelGGL(vote_kernel, dim3((uint32_t) vblocks), dim3(256), 0, stream, idx->view, ws->d_rec, ws->d_recq,
+        auto vk = vote_u == 2 ? vote_kernel<2> : vote_u == 8 ? vote_kernel<8> : vote_kernel<4>;
+        hipLaunchKernelGGL(vk, dim3((uint32_t) vblocks), dim3(256), 0, stream, idx->view, ws->d_rec, ws->d_recq,
                            ws->d_cnt, ws->d_hcount, dec, n, (int) seed_len, lo, hi, cap_q, tbits, t3_slots, t3_limit,
-                           ws->d_phase, ws->d_err);
+                           vg, t1_limit, ws->d_phase, ws->d_err);
         lrm_time_end(ws, stream);
         lrm_time_begin(ws, LRM_K_DECIDE, stream);
         hipLaunchKernelGGL(decide_kernel, dim3((uint32_t) ((n + 255) / 256)), dim3(256), 0, stream, ws->d_phase,

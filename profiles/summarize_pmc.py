@@ -10,14 +10,13 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
-LAUNCHES_PER_STEP = {"pack2bit_kernel": 1, "seed_search_kernel": 2, "vote_wave_kernel": 2, "vote_wave2_kernel": 4,
-                     "vote_block_kernel": 2, "decide_kernel": 2, "locus_resolve_kernel": 1, "revcomp_kernel": 1,
+LAUNCHES_PER_STEP = {"pack2bit_kernel": 1, "seed_search_kernel": 2, "vote_kernel": 2, "decide_kernel": 2, "locus_resolve_kernel": 1, "revcomp_kernel": 1,
                      "gact3_kernel": 1, "gact_kernel": 1, "gact_bs_kernel": 1, "bs_pack_reads_kernel": 1,
                      "bs_expand_kernel": 1}
 
@@ -98,6 +97,7 @@ def load(name):
 
 b1 = load("bench_streams1.json")
 bc = load("bench_chr1_pacbio15k.json")
+bu = load("bench_ultralong_20k_x_100kbp.json")
 stats1 = glob.glob(os.path.join(src, "trace_streams1", "*", "*_kernel_stats.csv"))
 if stats1:
     shutil.copy(stats1[0], os.path.join(dst, "kernel_stats_streams1.csv"))
@@ -114,8 +114,18 @@ with open(os.path.join(dst, "README.md"), "w") as f:
     if bc:
         f.write("`bench_chr1_pacbio15k.json`: human-chr1-sized text, 50 k x 15 kbp PacBio-CLR-profile reads: **%.2f Gbp/s**, "
                 "%.1f ms per 0.75-Gbp step.\n\n" % (bc["value"], bc["ms_per_step"]))
+    if bu:
+        f.write("`bench_ultralong_20k_x_100kbp.json`: 20 k x 100 kbp ONT-profile reads: **%.2f Gbp/s**, %.1f ms per 2-Gbp step.\n\n"
+                % (bu["value"], bu["ms_per_step"]))
+    if bench.get("pcie_inclusive"):
+        pi = bench["pcie_inclusive"]
+        f.write("PCIe-inclusive (SURVEY 8(d): `lrm_map_batch` on caller buffers, H2D of reads + D2H of results timed): pinned "
+                "**%.2f Gbp/s**, pageable %.2f Gbp/s.\n\n" % (pi["pinned"]["value"], pi["pageable"]["value"]))
     f.write("## HIP-event timing inside bench.py, default command (durations include the overlap with other steps' kernels)\n\n")
     f.write(event_table(bench))
+    if bench.get("isolated"):
+        f.write("\n## Serialized replay inside the same command (`isolated`: what `roofline` is taken from)\n\n")
+        f.write(event_table(bench["isolated"]))
     if stats:
         f.write("\n## rocprofv3 --kernel-trace --stats of the default command (`kernel_stats.csv`)\n\n" + stats_table(stats[0]))
     if b1:

@@ -58,17 +58,16 @@ def test_ont_10k_multi_sequence_with_repeats(ref3):
     assert near.mean() > 0.95
 
 
-@pytest.mark.parametrize("T,O,W", [(128, 32, 32), (128, 64, 64), (256, 64, 128), (256, 120, 64), (320, 120, 32),
-                                   (320, 32, 128), (512, 120, 128), (512, 64, 64),
-                                   (128, 32, 128), (256, 64, 256), (320, 120, 320), (512, 120, 512)])   # ... and W = T
-def test_ultralong_100k_gact_sweep(ref3, T, O, W):
+@pytest.mark.parametrize("T,O,W", [(128, 32, 32), (320, 120, 128), (512, 120, 128), (256, 64, 256)])
+def test_ultralong_100k_byte_kernels(ref3, T, O, W):
+    """Small batches take the byte kernels (two reads per wavefront / one read per wavefront for T - O > 256 /
+    wide band); the full sweep below runs the W <= 128 points on the bit-sliced kernel."""
     seqs, hi, di, oi = ref3
     r = synth.reads(seqs, 6, 100_000, synth.ONT, seed=17)
     _compare(di, oi, r["reads"], r["lens"], (T, O, W))
 
 
-@pytest.mark.parametrize("T,O,W", [(256, 64, 128), (320, 32, 128), (320, 120, 128), (512, 120, 128),
-                                   (128, 32, 32), (128, 64, 64), (256, 120, 64), (320, 120, 32), (512, 64, 64)])
+@pytest.mark.parametrize("T,O,W", [(320, 120, 128), (512, 64, 64)])
 def test_ultralong_100k_bitsliced(ref3, monkeypatch, T, O, W):
     """The W <= 128 points of the config-4 sweep through the lane-per-read kernel (500 tiles per read), reads of
     100 kbp next to short ones so that lanes finish at very different times."""
@@ -78,6 +77,42 @@ def test_ultralong_100k_bitsliced(ref3, monkeypatch, T, O, W):
     lens = r["lens"].copy()
     lens[1], lens[4] = 7_000, 333
     _compare(di, oi, r["reads"], lens, (T, O, W))
+
+
+SWEEP = sorted({(T, O, W) for T in (128, 256, 320, 512) for O in (32, 64, 120) for W in (32, 64, 128, T)})
+
+
+@pytest.fixture(scope="module")
+def ultralong(ref3):
+    seqs, hi, di, oi = ref3
+    r = synth.reads(seqs, 4, 100_000, synth.ONT, seed=23)
+    lens = r["lens"].copy()
+    lens[3] = 41_000                           # reads of different lengths finish at different times
+    want_best, _ = oi.seed_batch(r["reads"], lens, nthreads=8)
+    got_best = mapper.seed_batch(di, r["reads"], lens)
+    assert np.array_equal(got_best, want_best)
+    return r["reads"], lens, want_best
+
+
+@pytest.mark.parametrize("T,O,W", SWEEP, ids=["T%d-O%d-W%d" % p for p in SWEEP])
+def test_config5_full_gact_sweep(ref3, ultralong, monkeypatch, T, O, W):
+    """every point of T in {128,256,320,512} x O in {32,64,120} x W in {32,64,128,T} on
+    100 kbp reads (45 distinct points: W = T coincides with 128 for T = 128).  W <= 128 runs on the bit-sliced
+    lane-per-read kernel (what large batches use), W > 128 on the wide-band kernel; extension results are
+    compared with the oracle bit for bit (scores, op strings, rev-comped reads)."""
+    seqs, hi, di, oi = ref3
+    reads, lens, best = ultralong
+    if W <= 128:
+        monkeypatch.setenv("LRM_GACT_IMPL", "4")
+    rc, rg = reads.copy(), reads.copy()
+    want = oi.extend_batch(rc, lens, best, (T, O, W), nthreads=8)
+    got = mapper.extend_batch(di, rg, lens, best, (T, O, W))
+    assert np.array_equal(got["meta_r"], want["meta_r"]) and np.array_equal(got["score"], want["score"])
+    assert np.array_equal(got["n_ops"], want["n_ops"]) and np.array_equal(rc, rg)
+    for i in range(len(lens)):
+        k = int(want["n_ops"][i])
+        assert bytes(got["ops"][i, :k]) == bytes(want["ops"][i, :k]), i
+    assert (want["score"] >= 0).all()
 
 
 def test_pacbio_and_multiseq_bitsliced(ref3, monkeypatch):
