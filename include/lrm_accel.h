@@ -212,8 +212,8 @@ int lrm_extend_batch_dev(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint6
  * the stream): vote items per table tier, reads decided in
  * phase 0, GACT tiles.  For tests / bench bookkeeping only. */
 typedef struct lrm_stats {
-    uint64_t vote_tier2_items;      /* (read,phase) items voted by a whole workgroup in one pass (192 < hits <= 960) */
-    uint64_t vote_tier3_items;      /* ... in several passes over the workgroup table (hits > 960) */
+    uint64_t vote_tier2_items;      /* (read,phase) items voted by a whole workgroup in one pass (192 < hits <= 1152) */
+    uint64_t vote_tier3_items;      /* ... in several passes over the workgroup table (hits > 1152) */
     uint64_t reads_decided_phase0;  /* reads whose vote passed 0.6 in phase 0 */
     uint64_t gact_tiles;
 } lrm_stats;
@@ -235,6 +235,10 @@ const char *lrm_kernel_name(int kernel);
 int lrm_debug_seed_search(lrm_index *idx, const char *read, uint32_t len, uint32_t seed_len,
                           uint32_t thres, int32_t *j_out, uint64_t *rr_out, uint64_t *k_out,
                           uint64_t *l_out, uint64_t cap, uint64_t *n_out);
+
+/* RCCL self-test (tests only): dlopen + ncclCommInitAll + a 1-rank grouped ncclBroadcast of `bytes` bytes on
+ * `device`.  0 ok, 1 librccl not loadable (lrm_index_upload_multi then uses hipMemcpyPeer), <0 error. */
+int lrm_debug_rccl_selftest(int device, uint64_t bytes);
 
 /* Direct kernel tap (tests only): simple_gact on one (q, d) pair. */
 int lrm_debug_gact(const char *q, int n, const char *d, int m, lrm_gact_params gp,

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 ACCEL_SRCS = ["lrm_api.hip", "lrm_host.hip", "seed_kernels.hip", "gact_kernels.hip", "gact_bs_kernels.hip", "index_host.cpp", "io_host.cpp"]
 ACCEL_DEPS = ACCEL_SRCS + ["lrm_internal.h", "../../include/lrm_accel.h", "../../include/lrm_index_host.h",
                            "../../include/lrm_io_host.h"]
-ACCEL_LIB = os.path.join(HERE, "liblrm_accel.so")
+ACCEL_LIB = os.environ.get("LRM_ACCEL_LIB") or os.path.join(HERE, "liblrm_accel.so")     # LRM_ACCEL_LIB: a tuning build (tools/)
 SYNTH_LIB = os.path.join(HERE, "liblrm_synth.so")
 
 
@@ -41,21 +41,25 @@ def hipcc_path():
     return None
 
 
-def build_accel(force=False):
+def build_accel(force=False, defines=(), out=None):
     deps = [os.path.join(CSRC, d) for d in ACCEL_DEPS]
-    if not force and not _stale(ACCEL_LIB, deps):
-        return ACCEL_LIB
+    target = out or ACCEL_LIB
+    if os.environ.get("LRM_ACCEL_LIB") and not out:
+        return ACCEL_LIB                 # a tuning build chosen by the caller: use it as it is
+    if not force and not _stale(target, deps):
+        return target
     hipcc = hipcc_path()
     if hipcc is None:
-        if os.path.exists(ACCEL_LIB):
-            return ACCEL_LIB        # GPU box without a compiler on PATH: use the prebuilt library
+        if os.path.exists(target):
+            return target           # GPU box without a compiler on PATH: use the prebuilt library
         raise RuntimeError("hipcc not found and no prebuilt liblrm_accel.so")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fopenmp",
            "-I" + os.path.join(ROOT, "include")]
+    cmd += ["-D" + d for d in defines]
     cmd += [os.path.join(CSRC, s) for s in ACCEL_SRCS]
-    cmd += ["-lz", "-ldl", "-o", ACCEL_LIB]
+    cmd += ["-lz", "-ldl", "-o", target]
     _run(cmd)
-    return ACCEL_LIB
+    return target
 
 
 def build_synth(force=False):

@@ -122,6 +122,7 @@ SYMBOLS = {
     "lrm_kernel_name": (C.c_char_p, [C.c_int]),
     "lrm_debug_seed_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, u64p]),
+    "lrm_debug_rccl_selftest": (C.c_int, [C.c_int, C.c_uint64]),
     "lrm_debug_gact": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, GactParams, C.c_void_p,
                                  C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
     # lrm_index_host.h

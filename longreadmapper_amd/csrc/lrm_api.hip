@@ -579,6 +579,25 @@ extern "C" int lrm_index_upload_multi(lrm_index **out, const lrm_dna_fmi *fmi, c
     return 0;
 }
 
+// Test tap: the RCCL path of lrm_index_upload_multi on ONE device -- dlopen of librccl, ncclCommInitAll, a grouped
+// ncclBroadcast of `bytes` bytes on a 1-rank communicator, teardown.  A one-GPU box cannot run the multi-device
+// broadcast itself; this checks that the library loads and that the calls are bound with the right signatures.
+// Returns 0 ok, 1 RCCL not loadable (the multi-GPU upload then falls back to hipMemcpyPeer), -1 error.
+extern "C" int lrm_debug_rccl_selftest(int device, uint64_t bytes) {
+    if (lrm_require_device(device)) return -1;
+    void *d = nullptr;
+    if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) { lrm_set_error("hipMalloc failed"); return -1; }
+    std::vector<uint8_t> h(bytes ? bytes : 1);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (uint8_t) (i * 131u + 7u);
+    int rc = hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+    if (rc == 0) rc = rccl_broadcast(std::vector<int>{device}, std::vector<void *>{d}, (uint64_t) h.size());
+    std::vector<uint8_t> back(h.size());
+    if (rc == 0 && hipMemcpy(back.data(), d, h.size(), hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
+    if (rc == 0 && back != h) { lrm_set_error("RCCL self-test: buffer changed by a 1-rank broadcast"); rc = -1; }
+    (void) hipFree(d);
+    return rc;
+}
+
 extern "C" int lrm_index_replicas(const lrm_index *idx) { return idx ? idx->n_peers : 0; }
 extern "C" lrm_index *lrm_index_replica(lrm_index *idx, int r) {
     if (!idx || r < 0 || r >= idx->n_peers) return nullptr;
@@ -622,6 +641,13 @@ extern "C" uint64_t lrm_workspace_bytes(const lrm_workspace *ws) { return ws ? w
 
 extern "C" int lrm_workspace_create(lrm_workspace **out, lrm_index *idx, uint64_t n_max, uint32_t max_len,
                                     uint32_t seed_len, uint32_t thres) {
+    return lrm_workspace_create_parts(out, idx, n_max, max_len, seed_len, thres, LRM_WS_SEED | LRM_WS_EXTEND);
+}
+
+// parts: LRM_WS_SEED (packed reads, survivor lists, phase results), LRM_WS_EXTEND (planar reads, checkpoints, codes);
+// the host pipeline seeds in small sub-batches and extends in larger groups, each with the scratch it needs
+int lrm_workspace_create_parts(lrm_workspace **out, lrm_index *idx, uint64_t n_max, uint32_t max_len,
+                               uint32_t seed_len, uint32_t thres, int parts) {
     if (!out || !idx) { lrm_set_error("null argument"); return -1; }
     if (seed_len < 1 || seed_len > 32) { lrm_set_error("seed_len %u outside [1,32]", seed_len); return -1; }
     if (thres >= (1u << 24)) { lrm_set_error("thres %u >= 2^24 unsupported", thres); return -1; }
@@ -639,22 +665,24 @@ extern "C" int lrm_workspace_create(lrm_workspace **out, lrm_index *idx, uint64_
     ws->words_per_read = (uint64_t) max_len / 32 + 2;
     ws->qpl_wpr = lrm_bs_planar_words(max_len);
     ws->codes_cw = lrm_bs_code_words(max_len);
-    struct { void **p; uint64_t bytes; } allocs[] = {
-        {(void **) &ws->d_reads2, n_max * ws->words_per_read * 8},
-        {(void **) &ws->d_rec, n_max * (uint64_t) ws->P * ws->cap_q * 8},
-        {(void **) &ws->d_recq, n_max * (uint64_t) ws->P * ws->cap_q * 4},
-        {(void **) &ws->d_cnt, n_max * (uint64_t) ws->P * 4},
-        {(void **) &ws->d_phase, n_max * (uint64_t) ws->P * sizeof(LrmPhaseRes)},
-        {(void **) &ws->d_decided, n_max},
-        {(void **) &ws->d_hcount, n_max * (uint64_t) ws->P * 4},
-        {(void **) &ws->d_counters, sizeof(LrmDevCounters)},
-        {(void **) &ws->d_qpl, n_max * ws->qpl_wpr * 8 + 16},
-        {(void **) &ws->d_rflags, n_max * 4},
-        {(void **) &ws->d_ckpt, lrm_bs_ckpt_words(n_max) * 4},
-        {(void **) &ws->d_codes, n_max * ws->codes_cw * 8},
-        {(void **) &ws->d_ncodes, n_max * 4},
+    ws->parts = parts;
+    struct { void **p; uint64_t bytes; int part; } allocs[] = {
+        {(void **) &ws->d_reads2, n_max * ws->words_per_read * 8, LRM_WS_SEED},
+        {(void **) &ws->d_rec, n_max * (uint64_t) ws->P * ws->cap_q * 8, LRM_WS_SEED},
+        {(void **) &ws->d_recq, n_max * (uint64_t) ws->P * ws->cap_q * 4, LRM_WS_SEED},
+        {(void **) &ws->d_cnt, n_max * (uint64_t) ws->P * 4, LRM_WS_SEED},
+        {(void **) &ws->d_phase, n_max * (uint64_t) ws->P * sizeof(LrmPhaseRes), LRM_WS_SEED},
+        {(void **) &ws->d_decided, n_max, LRM_WS_SEED},
+        {(void **) &ws->d_hcount, n_max * (uint64_t) ws->P * 4, LRM_WS_SEED},
+        {(void **) &ws->d_counters, sizeof(LrmDevCounters), LRM_WS_SEED | LRM_WS_EXTEND},
+        {(void **) &ws->d_qpl, n_max * ws->qpl_wpr * 8 + 16, LRM_WS_EXTEND},
+        {(void **) &ws->d_rflags, n_max * 4, LRM_WS_EXTEND},
+        {(void **) &ws->d_ckpt, lrm_bs_ckpt_words(n_max) * 4, LRM_WS_EXTEND},
+        {(void **) &ws->d_codes, n_max * ws->codes_cw * 8, LRM_WS_EXTEND},
+        {(void **) &ws->d_ncodes, n_max * 4, LRM_WS_EXTEND},
     };
     for (auto &a : allocs) {
+        if (!(a.part & parts)) continue;
         if (hipMalloc(a.p, a.bytes) != hipSuccess) {
             lrm_set_error("hipMalloc of %llu workspace bytes failed", (unsigned long long) a.bytes);
             lrm_workspace_free(ws);
@@ -709,6 +737,7 @@ extern "C" int lrm_seed_batch_dev(lrm_index *idx, lrm_workspace *ws, const char 
                                   lrm_entry *d_best, void *stream) {
     if (!idx || !d_reads || !d_lens || !d_best) { lrm_set_error("null argument"); return -1; }
     if (check_ws(ws, idx, n, max_len, p.seed_len, p.thres)) return -1;
+    if (!(ws->parts & LRM_WS_SEED)) { lrm_set_error("workspace has no seed-stage scratch"); return -1; }
     if (stride < max_len) { lrm_set_error("stride %llu < max_len %u", (unsigned long long) stride, max_len); return -1; }
     if (lrm_ws_take_error(ws)) return -2;
     HIPCHK(hipSetDevice(idx->device));
@@ -738,9 +767,10 @@ extern "C" int lrm_workspace_stats(lrm_workspace *ws, lrm_stats *out, void *stre
     HIPCHK(hipStreamSynchronize((hipStream_t) stream));
     {   // tier occupancy from the per-(read,phase) hit counts of the last seed call (host-side count)
         std::vector<uint32_t> hc((size_t) ws->n_last * ws->P);
-        if (!hc.empty()) HIPCHK(hipMemcpy(hc.data(), ws->d_hcount, hc.size() * 4, hipMemcpyDeviceToHost));
+        if (!hc.empty() && ws->d_hcount) HIPCHK(hipMemcpy(hc.data(), ws->d_hcount, hc.size() * 4, hipMemcpyDeviceToHost));
+        else hc.clear();
         uint64_t t2 = 0, t3 = 0;
-        for (uint32_t h : hc) { t2 += (h > 192 && h <= 960); t3 += (h > 960); }
+        for (uint32_t h : hc) { t2 += (h > LRM_VOTE_T1_LIMIT && h <= LRM_VOTE_T3_LIMIT); t3 += (h > LRM_VOTE_T3_LIMIT); }
         out->vote_tier2_items = t2;
         out->vote_tier3_items = t3;
     }

@@ -6,21 +6,24 @@
 // thread per replica, every replica writes its slice of the caller's arrays in place -- SURVEY 8(b)/(e); the
 // host loop this replaces is alnmain.c:302-330).
 //
-// A batch goes through a device in sub-batches over THREE sets of device mirrors, each with its own compute
-// stream and workspace: while the kernels of sub-batch k run, the issuing thread uploads sub-batch k+1 (whose
-// seed kernels then overlap the extension of k: one is bound by memory latency, the other by VALU issue) and a
-// second host thread downloads the results of sub-batch k-1, so both directions of the link and the GPU are busy
-// at once.  Results leave the device DENSE: a pack kernel gathers the used part of every CIGAR row and the
-// reverse-complemented reads (the only rows of reads_buf that changed) into one contiguous buffer, which crosses
-// the link at the full DMA rate (a strided hipMemcpy2D of the same rows measured 6 GB/s against 57 GB/s flat) and
-// is scattered into the caller's rows by a multi-threaded memcpy.  Reads that are pinned (lrm_host_alloc /
-// lrm_host_register) are uploaded by the DMA engines directly; pageable ones (what alnmain.c mallocs) are staged
-// chunk-wise through pinned memory, the host half of every chunk overlapping the DMA of the previous chunk.
+// How a slice of a batch goes through a device: its arrays are mirrored whole in HBM; the reads are uploaded and
+// SEEDED in sub-batches (three seed streams, round robin: the first kernels start a few milliseconds into the
+// call and the uploads hide behind them), the EXTENSION runs over groups of sub-batches on its own stream as soon
+// as their seeds are done (the bit-sliced kernel carries one read per lane and wants ~25 k reads per launch;
+// the memory-latency-bound seed kernels of later sub-batches overlap its VALU-bound work), and a second host
+// thread downloads every group while the next one is extended.  Results leave the device DENSE: a pack kernel
+// gathers the used part of every CIGAR row and the reverse-complemented reads (the only rows of reads_buf that
+// changed) into one contiguous buffer, which crosses the link at the full DMA rate (a strided hipMemcpy2D of the
+// same rows measured 6 GB/s against 57 GB/s flat) and is scattered into the caller's rows by a multi-threaded
+// memcpy.  Reads that are pinned (lrm_host_alloc / lrm_host_register) are uploaded by the DMA engines directly;
+// pageable ones (what alnmain.c mallocs) are staged chunk-wise through pinned memory, the host half of every chunk
+// overlapping the DMA of the previous chunk.
 // No CPU fallback: without a HIP device every entry point fails.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -33,6 +36,13 @@
     lrm_set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
 
 namespace {
+
+// LRM_HOST_VERBOSE=1: stage times of the host-buffer pipeline on stderr (tuning aid)
+struct HostClock {
+    bool on = getenv("LRM_HOST_VERBOSE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 struct DevSlot {
     void *p = nullptr; uint64_t cap = 0;
@@ -47,7 +57,7 @@ struct DevSlot {
     void release() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
 };
 constexpr uint64_t STAGE_CHUNK = 32ull << 20;
-constexpr int N_SETS = 3;
+constexpr int N_SEED_STREAMS = 3;
 constexpr int COPY_THREADS = 8;       // enough to outrun the link; a library must not fan out over every core of its host
 struct DevSet { DevSlot reads, lens, best, store, nops, score, meta, mr, dense, offs; };
 
@@ -55,12 +65,13 @@ struct DevSet { DevSlot reads, lens, best, store, nops, score, meta, mr, dense, 
 
 struct LrmHostCtx {
     std::mutex mu;                       // one host-buffer call at a time per replica (re-entrant per handle otherwise)
-    lrm_workspace *ws[N_SETS] = {};      // one workspace and one compute stream per set of mirrors
-    DevSet set[N_SETS];
+    lrm_workspace *ws_seed[N_SEED_STREAMS] = {};   // seed-stage scratch, one per seed stream (sub-batch sized)
+    lrm_workspace *ws_ext = nullptr;               // extension scratch (group sized)
+    DevSet dev;                                    // device mirrors of the caller's arrays for one slice
     void *pin_up[2] = {nullptr, nullptr}, *pin_dn[2] = {nullptr, nullptr};
-    hipStream_t up = nullptr, down = nullptr, comp[N_SETS] = {};
+    hipStream_t up = nullptr, down = nullptr, seed[N_SEED_STREAMS] = {}, ext = nullptr;
     hipEvent_t ev_pin_up[2] = {nullptr, nullptr}, ev_pin_dn[2] = {nullptr, nullptr};
-    hipEvent_t ev_up[N_SETS] = {}, ev_done[N_SETS] = {};
+    std::vector<hipEvent_t> ev_up, ev_seed, ev_ext;   // per sub-batch / per extension group, grown on demand
     bool pin_up_used[2] = {false, false};
     uint64_t up_seq = 0;
     bool ready = false;
@@ -76,14 +87,27 @@ int ctx_init(LrmHostCtx &c) {
         if (hipEventCreateWithFlags(&c.ev_pin_up[b], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c.ev_pin_dn[b], hipEventDisableTiming) != hipSuccess) { lrm_set_error("event creation failed"); return -1; }
     }
-    for (int s = 0; s < N_SETS; ++s)
-        if (hipEventCreateWithFlags(&c.ev_up[s], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c.ev_done[s], hipEventDisableTiming) != hipSuccess) { lrm_set_error("event creation failed"); return -1; }
-    if (hipStreamCreateWithFlags(&c.up, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c.down, hipStreamNonBlocking) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
-    for (int s = 0; s < N_SETS; ++s)
-        if (hipStreamCreateWithFlags(&c.comp[s], hipStreamNonBlocking) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
+    // Priorities: the result path first (pack kernels + downloads), then the extension of a finished group, then
+    // the seed kernels of later sub-batches -- otherwise every group's extension finishes at the very end, behind
+    // all the seed work, and the downloads of all but the first group run after the compute instead of under it.
+    int prio_lo = 0, prio_hi = 0;
+    (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);          // numerically lower = higher priority
+    const int p_seed = prio_lo, p_ext = prio_hi < prio_lo ? prio_lo - 1 : prio_lo, p_down = prio_hi;
+    if (hipStreamCreateWithPriority(&c.up, hipStreamNonBlocking, p_down) != hipSuccess ||
+        hipStreamCreateWithPriority(&c.down, hipStreamNonBlocking, p_down) != hipSuccess ||
+        hipStreamCreateWithPriority(&c.ext, hipStreamNonBlocking, p_ext) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
+    for (int s = 0; s < N_SEED_STREAMS; ++s)
+        if (hipStreamCreateWithPriority(&c.seed[s], hipStreamNonBlocking, p_seed) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
     c.ready = true;
+    return 0;
+}
+
+int ensure_events(std::vector<hipEvent_t> &v, size_t n) {
+    while (v.size() < n) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { lrm_set_error("event creation failed"); return -1; }
+        v.push_back(e);
+    }
     return 0;
 }
 
@@ -218,13 +242,21 @@ uint64_t host_slice_reads(uint32_t max_len) {
     return r < 16384 ? 16384 : r;
 }
 
-// Sub-batches of one device pass (see the header comment); at least LRM_PIPE_MIN_READS reads each, because the
-// bit-sliced extension needs that many to fill the chip.
-constexpr uint64_t PIPE_MIN_READS = 16384;
+// Seed sub-batches of one device pass (see the header comment): small enough that the first kernels start a few
+// milliseconds after the call and the uploads hide behind them.
+constexpr uint64_t PIPE_MIN_READS = 8192;
 uint64_t pipe_subs(uint64_t n) {
     if (const char *e = getenv("LRM_HOST_SUBS")) { const long long v = atoll(e); if (v >= 1) return (uint64_t) v < n ? (uint64_t) v : n; }   // test knob
     const uint64_t k = n / PIPE_MIN_READS;
-    return k < 2 ? 1 : (k > 6 ? 6 : k);
+    return k < 2 ? 1 : (k > 12 ? 12 : k);
+}
+// Sub-batches per extension group: the bit-sliced kernel carries one read per LANE, so it wants >= 32 k reads
+// per launch to put a wavefront on a good part of the chip's SIMDs (measured: 25 k-read groups beat 37 k and 17 k).
+constexpr uint64_t EXT_GROUP_READS = 24576;
+uint64_t ext_group_subs(uint64_t sub, uint64_t nsub) {
+    if (const char *e = getenv("LRM_HOST_GROUP")) { const long long v = atoll(e); if (v >= 1) return (uint64_t) v < nsub ? (uint64_t) v : nsub; }   // test knob
+    const uint64_t g = (EXT_GROUP_READS + sub - 1) / (sub ? sub : 1);
+    return g < 1 ? 1 : (g > nsub ? nsub : g);
 }
 
 enum { DO_SEED = 1, DO_EXTEND = 2 };
@@ -244,21 +276,17 @@ struct MapJob {
     }
 };
 
-int get_ws(LrmHostCtx &c, int s, lrm_index *idx, uint64_t n, uint32_t max_len, uint32_t seed_len, uint32_t thres, bool exact) {
-    lrm_workspace *ws = c.ws[s];
-    if (ws && n <= ws->n_max && max_len <= ws->max_len && (!exact || (seed_len == ws->seed_len && thres <= ws->thres))) return 0;
-    if (ws && !exact) { seed_len = ws->seed_len; thres = ws->thres; }     // extend only: keep the seed shape of the cached one
-    if (ws) { lrm_workspace_free(ws); c.ws[s] = nullptr; }
-    if (lrm_workspace_create(&ws, idx, n, max_len, seed_len, thres)) return -1;
-    c.ws[s] = ws;
-    return 0;
+int get_ws(lrm_workspace *&ws, lrm_index *idx, uint64_t n, uint32_t max_len, uint32_t seed_len, uint32_t thres, int parts) {
+    if (ws && n <= ws->n_max && max_len <= ws->max_len && (!(parts & LRM_WS_SEED) || (seed_len == ws->seed_len && thres <= ws->thres))) return 0;
+    if (ws) { lrm_workspace_free(ws); ws = nullptr; }
+    return lrm_workspace_create_parts(&ws, idx, n, max_len, seed_len, thres, parts);
 }
 
 // hand-off between the issuing thread and the download thread
 struct Pipe {
     std::mutex m;
     std::condition_variable cv;
-    uint64_t issued = 0, collected = 0;
+    uint64_t issued = 0;              // units (extension groups, or seed sub-batches in seed-only mode) handed to the device
     bool stop = false;
     int rc = 0;
     char err[512] = "";
@@ -269,21 +297,30 @@ struct Pipe {
     }
 };
 
-struct SubBatch { uint64_t off, m; };
+struct Range { uint64_t off, m; };
 
-// download of sub-batch k (runs on the download thread once ev_done[k % N_SETS] has fired)
-int collect(LrmHostCtx &c, const MapJob &j, const SubBatch &sb, int s, uint64_t dstride) {
-    DevSet &d = c.set[s];
-    HIPCHK(hipEventSynchronize(c.ev_done[s]));
-    if (lrm_ws_take_error(c.ws[s])) return -2;                     // raised by this or an earlier sub-batch: never lost
-    const uint64_t m = sb.m, o = sb.off;
-    if (j.mode & DO_SEED) HIPCHK(hipMemcpyAsync(j.best_out + o, d.best.p, m * sizeof(lrm_entry), hipMemcpyDeviceToHost, c.down));
+int take_errors(LrmHostCtx &c) {
+    int rc = 0;
+    for (int s = 0; s < N_SEED_STREAMS; ++s) if (lrm_ws_take_error(c.ws_seed[s])) rc = -2;
+    if (lrm_ws_take_error(c.ws_ext)) rc = -2;
+    return rc;
+}
+
+// download of one unit [off, off + m) of the slice (runs on the download thread once `done` has fired)
+int collect(LrmHostCtx &c, const MapJob &j, const Range &u, hipEvent_t done, uint64_t dstride, const HostClock &clk) {
+    DevSet &d = c.dev;
+    const double t_in = clk.ms();
+    HIPCHK(hipEventSynchronize(done));
+    const double t_done = clk.ms();
+    if (take_errors(c)) return -2;                                   // raised by this or an earlier unit: never lost
+    const uint64_t m = u.m, o = u.off;
+    if (j.mode & DO_SEED) HIPCHK(hipMemcpyAsync(j.best_out + o, (const lrm_entry *) d.best.p + o, m * sizeof(lrm_entry), hipMemcpyDeviceToHost, c.down));
     if (!(j.mode & DO_EXTEND)) { HIPCHK(hipStreamSynchronize(c.down)); return 0; }
     std::vector<int32_t> nops(m);
-    HIPCHK(hipMemcpyAsync(nops.data(), d.nops.p, m * 4, hipMemcpyDeviceToHost, c.down));
-    HIPCHK(hipMemcpyAsync(j.score + o, d.score.p, m * 4, hipMemcpyDeviceToHost, c.down));
-    HIPCHK(hipMemcpyAsync(j.meta + o, d.meta.p, m * sizeof(lrm_seq_meta), hipMemcpyDeviceToHost, c.down));
-    HIPCHK(hipMemcpyAsync(j.meta_r + o, d.mr.p, m * 4, hipMemcpyDeviceToHost, c.down));
+    HIPCHK(hipMemcpyAsync(nops.data(), (const int32_t *) d.nops.p + o, m * 4, hipMemcpyDeviceToHost, c.down));
+    HIPCHK(hipMemcpyAsync(j.score + o, (const int32_t *) d.score.p + o, m * 4, hipMemcpyDeviceToHost, c.down));
+    HIPCHK(hipMemcpyAsync(j.meta + o, (const lrm_seq_meta *) d.meta.p + o, m * sizeof(lrm_seq_meta), hipMemcpyDeviceToHost, c.down));
+    HIPCHK(hipMemcpyAsync(j.meta_r + o, (const int32_t *) d.mr.p + o, m * 4, hipMemcpyDeviceToHost, c.down));
     HIPCHK(hipStreamSynchronize(c.down));
     // dense layout: the used part of every CIGAR row, then the reads that were reverse-complemented in place
     // (alnmain.c:437; the other rows of reads_buf did not change)
@@ -303,123 +340,152 @@ int collect(LrmHostCtx &c, const MapJob &j, const SubBatch &sb, int s, uint64_t 
         off[m + i] = total;
         total += ((uint64_t) len[m + i] + 15) & ~15ull;
     }
+    const uint8_t *d_store = (const uint8_t *) d.store.p + o * dstride, *d_reads = (const uint8_t *) d.reads.p + o * j.stride;
     void *store_alias = nullptr, *reads_alias = nullptr;
-    const bool direct = getenv("LRM_HOST_NO_DIRECT") == nullptr &&
+    const bool direct = getenv("LRM_HOST_DIRECT") != nullptr &&
                         is_pinned(j.store_mem + o * j.store_stride, &store_alias) && store_alias &&
                         is_pinned(j.reads + o * j.stride, &reads_alias) && reads_alias;
-    if (total && direct) {
-        // pinned caller buffers: the device writes the rows straight into them (no dense staging, no host copy)
+    if (total) {
         if (d.offs.ensure(2 * m * 12)) { lrm_set_error("device allocation failed"); return -1; }
-        uint32_t *d_len = (uint32_t *) ((uint8_t *) d.offs.p + 2 * m * 8);
-        HIPCHK(hipMemcpyAsync(d_len, len.data(), 2 * m * 4, hipMemcpyHostToDevice, c.down));
-        const uint32_t gy_ops = (uint32_t) ((j.store_stride + 4095) / 4096), gy_rd = (uint32_t) ((j.stride + 4095) / 4096);
-        hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t) m, gy_ops ? gy_ops : 1), dim3(256), 0, c.down, (const uint8_t *) d.store.p,
-                           dstride, (uint8_t *) store_alias, j.store_stride, d_len, m);
-        hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t) m, gy_rd ? gy_rd : 1), dim3(256), 0, c.down, (const uint8_t *) d.reads.p,
-                           j.stride, (uint8_t *) reads_alias, j.stride, d_len + m, m);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c.down));
-    } else if (total) {
-        if (d.dense.ensure(total) || d.offs.ensure(2 * m * 12)) { lrm_set_error("device allocation failed"); return -1; }
         uint64_t *d_off = (uint64_t *) d.offs.p;
         uint32_t *d_len = (uint32_t *) ((uint8_t *) d.offs.p + 2 * m * 8);
-        HIPCHK(hipMemcpyAsync(d_off, off.data(), 2 * m * 8, hipMemcpyHostToDevice, c.down));
         HIPCHK(hipMemcpyAsync(d_len, len.data(), 2 * m * 4, hipMemcpyHostToDevice, c.down));
         const uint32_t gy_ops = (uint32_t) ((j.store_stride + 4095) / 4096), gy_rd = (uint32_t) ((j.stride + 4095) / 4096);
-        hipLaunchKernelGGL(pack_rows_kernel, dim3((uint32_t) m, gy_ops ? gy_ops : 1), dim3(256), 0, c.down, (const uint8_t *) d.store.p,
-                           dstride, d_len, d_off, (uint8_t *) d.dense.p, m);
-        hipLaunchKernelGGL(pack_rows_kernel, dim3((uint32_t) m, gy_rd ? gy_rd : 1), dim3(256), 0, c.down, (const uint8_t *) d.reads.p,
-                           j.stride, d_len + m, d_off + m, (uint8_t *) d.dense.p, m);
-        HIPCHK(hipGetLastError());
-        if (d2h_dense(c, j.store_mem + o * j.store_stride, j.store_stride, (const uint8_t *) d.dense.p, total_ops, off.data(),
-                      len.data(), m)) return -1;
-        // the reads part: offsets relative to its own start
-        for (uint64_t i = 0; i < m; ++i) off[m + i] -= total_ops;
-        if (d2h_dense(c, (uint8_t *) j.reads + o * j.stride, j.stride, (const uint8_t *) d.dense.p + total_ops, total - total_ops,
-                      off.data() + m, len.data() + m, m)) return -1;
+        if (direct) {
+            // LRM_HOST_DIRECT=1 with pinned caller buffers: the device writes the rows straight into them as posted
+            // writes.  Measured slower than the dense DMA + host scatter on this platform (23 GB/s against 57), so off
+            // by default.
+            hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t) m, gy_ops ? gy_ops : 1), dim3(256), 0, c.down, d_store, dstride,
+                               (uint8_t *) store_alias, j.store_stride, d_len, m);
+            hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t) m, gy_rd ? gy_rd : 1), dim3(256), 0, c.down, d_reads, j.stride,
+                               (uint8_t *) reads_alias, j.stride, d_len + m, m);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(c.down));
+        } else {
+            if (d.dense.ensure(total)) { lrm_set_error("device allocation failed"); return -1; }
+            HIPCHK(hipMemcpyAsync(d_off, off.data(), 2 * m * 8, hipMemcpyHostToDevice, c.down));
+            hipLaunchKernelGGL(pack_rows_kernel, dim3((uint32_t) m, gy_ops ? gy_ops : 1), dim3(256), 0, c.down, d_store, dstride,
+                               d_len, d_off, (uint8_t *) d.dense.p, m);
+            hipLaunchKernelGGL(pack_rows_kernel, dim3((uint32_t) m, gy_rd ? gy_rd : 1), dim3(256), 0, c.down, d_reads, j.stride,
+                               d_len + m, d_off + m, (uint8_t *) d.dense.p, m);
+            HIPCHK(hipGetLastError());
+            if (d2h_dense(c, j.store_mem + o * j.store_stride, j.store_stride, (const uint8_t *) d.dense.p, total_ops, off.data(),
+                          len.data(), m)) return -1;
+            for (uint64_t i = 0; i < m; ++i) off[m + i] -= total_ops;        // the reads part: offsets relative to its own start
+            if (d2h_dense(c, (uint8_t *) j.reads + o * j.stride, j.stride, (const uint8_t *) d.dense.p + total_ops, total - total_ops,
+                          off.data() + m, len.data() + m, m)) return -1;
+        }
     }
     for (uint64_t i = 0; i < m; ++i) {                               // alnmain.c:322-325, mutils.c:99-104
         j.cig[o + i].cigar = j.store_mem + (o + i) * j.store_stride;
         j.cig[o + i].n_cigar_op = nops[i];
         j.cig[o + i].score = j.score[o + i];
     }
+    if (clk.on) fprintf(stderr, "[lrm host] collect off=%llu m=%llu: wait-from %.1f kernels-done %.1f collected %.1f ms (%s, %.0f MB)\n",
+                        (unsigned long long) o, (unsigned long long) m, t_in, t_done, clk.ms(), direct ? "direct" : "dense", total / 1e6);
     return 0;
 }
 
-// one device pass over a slice of the job: the three-stage pipeline
+// One device pass over a slice of the job.  The slice's arrays are mirrored whole on the device; the reads are
+// uploaded and SEEDED in sub-batches (seed streams, round robin), the EXTENSION runs over groups of sub-batches on
+// its own stream as soon as their seeds are done, and the download thread collects every group while the next one
+// is still being extended.
 int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) {
     const uint64_t n = j.n, nsub = pipe_subs(n), sub = (n + nsub - 1) / nsub;
     const uint64_t dstride = (j.store_stride + 3) & ~3ull;           // the bit-sliced kernel stores CIGAR bytes four at a time
     const bool pin_reads = is_pinned(j.reads);
-    std::vector<SubBatch> subs;
+    std::vector<Range> subs, units;
     for (uint64_t off = 0; off < n; off += sub) subs.push_back({off, n - off < sub ? n - off : sub});
-    if (subs.size() > 0x7fffffffull || sub > 0x7fffffffull) { lrm_set_error("batch too large"); return -1; }
-    const int nsets = subs.size() < (size_t) N_SETS ? (int) subs.size() : N_SETS;
-    for (int s = 0; s < nsets; ++s)
-        if (get_ws(c, s, idx, sub, max_len, j.p.seed_len, j.p.thres, (j.mode & DO_SEED) != 0)) return -1;
+    const uint64_t gsub = (j.mode & DO_EXTEND) ? ext_group_subs(sub, subs.size()) : 1;
+    for (size_t k = 0; k < subs.size(); k += gsub) {
+        const size_t e = k + gsub < subs.size() ? k + gsub : subs.size();
+        units.push_back({subs[k].off, subs[e - 1].off + subs[e - 1].m - subs[k].off});
+    }
+    uint64_t unit_max = 0;
+    for (auto &u : units) unit_max = u.m > unit_max ? u.m : unit_max;
+    if (n > 0x7fffffffull) { lrm_set_error("batch too large"); return -1; }
+    if (j.mode & DO_SEED)
+        for (int s = 0; s < N_SEED_STREAMS && (size_t) s < subs.size(); ++s)
+            if (get_ws(c.ws_seed[s], idx, sub, max_len, j.p.seed_len, j.p.thres, LRM_WS_SEED)) return -1;
+    if ((j.mode & DO_EXTEND) && get_ws(c.ws_ext, idx, unit_max, max_len, 20, 300, LRM_WS_EXTEND)) return -1;
+    if (ensure_events(c.ev_up, subs.size()) || ensure_events(c.ev_seed, subs.size()) || ensure_events(c.ev_ext, units.size())) return -1;
+    DevSet &d = c.dev;
+    if (d.reads.ensure(n * j.stride) || d.lens.ensure(n * 4) || d.best.ensure(n * sizeof(lrm_entry))) { lrm_set_error("device allocation failed"); return -1; }
+    if ((j.mode & DO_EXTEND) && (d.store.ensure(n * dstride) || d.nops.ensure(n * 4) || d.score.ensure(n * 4) ||
+                                  d.meta.ensure(n * sizeof(lrm_seq_meta)) || d.mr.ensure(n * 4))) { lrm_set_error("device allocation failed"); return -1; }
 
     Pipe pipe;
+    HostClock clk;
     const int device = idx->device;
+    const bool seed_only = !(j.mode & DO_EXTEND);
     std::thread downloader([&]() {
         if (hipSetDevice(device) != hipSuccess) { lrm_set_error("hipSetDevice failed on the download thread"); pipe.fail(-1); return; }
-        for (uint64_t k = 0; k < subs.size(); ++k) {
+        for (uint64_t g = 0; g < units.size(); ++g) {
             {
-                std::unique_lock<std::mutex> g(pipe.m);
-                pipe.cv.wait(g, [&] { return pipe.issued > k || pipe.stop || pipe.rc; });
-                if (pipe.rc || pipe.issued <= k) return;
+                std::unique_lock<std::mutex> lk(pipe.m);
+                pipe.cv.wait(lk, [&] { return pipe.issued > g || pipe.stop || pipe.rc; });
+                if (pipe.rc || pipe.issued <= g) return;
             }
-            const int rc = collect(c, j, subs[k], (int) (k % N_SETS), dstride);
+            // seed-only: a unit is done when the seeds of its last sub-batch are (sub-batches of a seed stream are ordered)
+            hipEvent_t done = seed_only ? c.ev_seed[(g + 1) * gsub - 1 < subs.size() ? (g + 1) * gsub - 1 : subs.size() - 1] : c.ev_ext[g];
+            const int rc = collect(c, j, units[g], done, dstride, clk);
             if (rc) { pipe.fail(rc); return; }
-            { std::lock_guard<std::mutex> g(pipe.m); pipe.collected = k + 1; }
-            pipe.cv.notify_all();
         }
     });
 
     int rc = 0;
+    int n_seed_streams = 2;
+    if (const char *e = getenv("LRM_HOST_SEED_STREAMS")) { const int v = atoi(e); if (v >= 1 && v <= N_SEED_STREAMS) n_seed_streams = v; }   // tuning knob
     for (uint64_t k = 0; k < subs.size() && !rc; ++k) {
-        const int s = (int) (k % N_SETS);
+        const int s = (int) (k % (uint64_t) n_seed_streams);
         const uint64_t m = subs[k].m, off = subs[k].off;
-        {   // the set's previous occupant (sub-batch k - N_SETS) has been downloaded
-            std::unique_lock<std::mutex> g(pipe.m);
-            pipe.cv.wait(g, [&] { return pipe.collected + N_SETS > k || pipe.rc; });
-            if (pipe.rc) break;
-        }
-        DevSet &d = c.set[s];
-        lrm_workspace *ws = c.ws[s];
-        hipStream_t comp = c.comp[s];
+        { std::lock_guard<std::mutex> lk(pipe.m); if (pipe.rc) break; }
         auto issue = [&]() -> int {
-            if (d.reads.ensure(m * j.stride) || d.lens.ensure(m * 4) || d.best.ensure(m * sizeof(lrm_entry))) { lrm_set_error("device allocation failed"); return -1; }
-            if ((j.mode & DO_EXTEND) && (d.store.ensure(m * dstride) || d.nops.ensure(m * 4) || d.score.ensure(m * 4) ||
-                                          d.meta.ensure(m * sizeof(lrm_seq_meta)) || d.mr.ensure(m * 4))) { lrm_set_error("device allocation failed"); return -1; }
-            if (h2d(c, d.reads.p, j.reads + off * j.stride, m * j.stride, pin_reads)) return -1;
-            HIPCHK(hipMemcpyAsync(d.lens.p, j.lens + off, m * 4, hipMemcpyHostToDevice, c.up));
-            if (!(j.mode & DO_SEED)) HIPCHK(hipMemcpyAsync(d.best.p, j.best_in + off, m * sizeof(lrm_entry), hipMemcpyHostToDevice, c.up));
-            HIPCHK(hipEventRecord(c.ev_up[s], c.up));
-            HIPCHK(hipStreamWaitEvent(comp, c.ev_up[s], 0));
-            if ((j.mode & DO_SEED) && lrm_launch_seed(idx, ws, (const char *) d.reads.p, j.stride, (const uint32_t *) d.lens.p, m, max_len,
-                                                      j.p.seed_len, j.p.thres, (lrm_entry *) d.best.p, comp)) return -1;
-            if ((j.mode & DO_EXTEND) && lrm_launch_extend(idx, ws, (char *) d.reads.p, j.stride, (const uint32_t *) d.lens.p, m, max_len,
-                                                          (const lrm_entry *) d.best.p, j.gp, (uint8_t *) d.store.p, dstride,
-                                                          (int32_t *) d.nops.p, (int32_t *) d.score.p, (lrm_seq_meta *) d.meta.p,
-                                                          (int32_t *) d.mr.p, comp)) return -1;
-            HIPCHK(hipEventRecord(c.ev_done[s], comp));
+            char *dr = (char *) d.reads.p + off * j.stride;
+            if (h2d(c, dr, j.reads + off * j.stride, m * j.stride, pin_reads)) return -1;
+            HIPCHK(hipMemcpyAsync((uint32_t *) d.lens.p + off, j.lens + off, m * 4, hipMemcpyHostToDevice, c.up));
+            if (!(j.mode & DO_SEED)) HIPCHK(hipMemcpyAsync((lrm_entry *) d.best.p + off, j.best_in + off, m * sizeof(lrm_entry), hipMemcpyHostToDevice, c.up));
+            HIPCHK(hipEventRecord(c.ev_up[k], c.up));
+            if (j.mode & DO_SEED) {
+                HIPCHK(hipStreamWaitEvent(c.seed[s], c.ev_up[k], 0));
+                if (lrm_launch_seed(idx, c.ws_seed[s], dr, j.stride, (const uint32_t *) d.lens.p + off, m, max_len, j.p.seed_len, j.p.thres,
+                                    (lrm_entry *) d.best.p + off, c.seed[s])) return -1;
+                HIPCHK(hipEventRecord(c.ev_seed[k], c.seed[s]));
+            }
+            const uint64_t g = k / gsub;
+            const bool closes = (k + 1) % gsub == 0 || k + 1 == subs.size();
+            if (closes && (j.mode & DO_EXTEND)) {                                  // the group's extension, behind its seeds / uploads
+                for (uint64_t x = g * gsub; x <= k; ++x) HIPCHK(hipStreamWaitEvent(c.ext, (j.mode & DO_SEED) ? c.ev_seed[x] : c.ev_up[x], 0));
+                const Range &u = units[g];
+                if (lrm_launch_extend(idx, c.ws_ext, (char *) d.reads.p + u.off * j.stride, j.stride, (const uint32_t *) d.lens.p + u.off, u.m,
+                                      max_len, (const lrm_entry *) d.best.p + u.off, j.gp, (uint8_t *) d.store.p + u.off * dstride, dstride,
+                                      (int32_t *) d.nops.p + u.off, (int32_t *) d.score.p + u.off, (lrm_seq_meta *) d.meta.p + u.off,
+                                      (int32_t *) d.mr.p + u.off, c.ext)) return -1;
+                HIPCHK(hipEventRecord(c.ev_ext[g], c.ext));
+            }
+            if (closes) {
+                { std::lock_guard<std::mutex> lk(pipe.m); pipe.issued = g + 1; }
+                pipe.cv.notify_all();
+            }
             return 0;
         };
+        const double t_i0 = clk.ms();
         rc = issue();
+        if (clk.on) fprintf(stderr, "[lrm host] issue   off=%llu m=%llu: %.1f -> %.1f ms\n", (unsigned long long) off, (unsigned long long) m, t_i0, clk.ms());
         if (rc) { pipe.fail(rc); break; }
-        { std::lock_guard<std::mutex> g(pipe.m); pipe.issued = k + 1; }
-        pipe.cv.notify_all();
     }
-    { std::lock_guard<std::mutex> g(pipe.m); pipe.stop = true; }
+    { std::lock_guard<std::mutex> lk(pipe.m); pipe.stop = true; }
     pipe.cv.notify_all();
     downloader.join();
+    if (clk.on) fprintf(stderr, "[lrm host] slice of %llu reads, %zu seed sub-batches, %zu units: %.1f ms\n", (unsigned long long) n, subs.size(), units.size(), clk.ms());
     if (pipe.rc) {
-        for (int s = 0; s < N_SETS; ++s) (void) hipStreamSynchronize(c.comp[s]);
-        (void) hipStreamSynchronize(c.up); (void) hipStreamSynchronize(c.down);
-        for (int s = 0; s < N_SETS; ++s) if (c.ws[s] && c.ws[s]->h_err) *c.ws[s]->h_err = 0;   // reported now: do not fail the next call
+        for (int s = 0; s < N_SEED_STREAMS; ++s) (void) hipStreamSynchronize(c.seed[s]);
+        (void) hipStreamSynchronize(c.ext); (void) hipStreamSynchronize(c.up); (void) hipStreamSynchronize(c.down);
+        (void) take_errors(c);                                        // reported now: do not fail the next call
         lrm_set_error("%s", pipe.err);
         return pipe.rc;
     }
+    // the device mirrors are reused by the next slice: everything must have drained (it has: every unit was collected)
     return 0;
 }
 
@@ -488,21 +554,21 @@ void lrm_host_ctx_free(lrm_index *idx) {
     if (!c) return;
     idx->host = nullptr;
     if (c->ready) {
-        for (int s = 0; s < N_SETS; ++s) (void) hipStreamSynchronize(c->comp[s]);
-        (void) hipStreamSynchronize(c->up); (void) hipStreamSynchronize(c->down);
+        for (int s = 0; s < N_SEED_STREAMS; ++s) (void) hipStreamSynchronize(c->seed[s]);
+        (void) hipStreamSynchronize(c->ext); (void) hipStreamSynchronize(c->up); (void) hipStreamSynchronize(c->down);
         for (int b = 0; b < 2; ++b) {
             (void) hipHostFree(c->pin_up[b]); (void) hipHostFree(c->pin_dn[b]);
             (void) hipEventDestroy(c->ev_pin_up[b]); (void) hipEventDestroy(c->ev_pin_dn[b]);
         }
-        for (int s = 0; s < N_SETS; ++s) { (void) hipEventDestroy(c->ev_up[s]); (void) hipEventDestroy(c->ev_done[s]); }
-        (void) hipStreamDestroy(c->up); (void) hipStreamDestroy(c->down);
-        for (int s = 0; s < N_SETS; ++s) (void) hipStreamDestroy(c->comp[s]);
+        (void) hipStreamDestroy(c->up); (void) hipStreamDestroy(c->down); (void) hipStreamDestroy(c->ext);
+        for (int s = 0; s < N_SEED_STREAMS; ++s) (void) hipStreamDestroy(c->seed[s]);
     }
-    for (int s = 0; s < N_SETS; ++s) if (c->ws[s]) lrm_workspace_free(c->ws[s]);
-    for (auto &d : c->set) {
-        d.reads.release(); d.lens.release(); d.best.release(); d.store.release();
-        d.nops.release(); d.score.release(); d.meta.release(); d.mr.release(); d.dense.release(); d.offs.release();
-    }
+    for (auto *v : {&c->ev_up, &c->ev_seed, &c->ev_ext}) for (hipEvent_t e : *v) (void) hipEventDestroy(e);
+    for (int s = 0; s < N_SEED_STREAMS; ++s) if (c->ws_seed[s]) lrm_workspace_free(c->ws_seed[s]);
+    if (c->ws_ext) lrm_workspace_free(c->ws_ext);
+    DevSet &d = c->dev;
+    d.reads.release(); d.lens.release(); d.best.release(); d.store.release();
+    d.nops.release(); d.score.release(); d.meta.release(); d.mr.release(); d.dense.release(); d.offs.release();
     delete c;
 }
 

@@ -113,14 +113,20 @@ struct LrmDevCounters {
 // sub-batch survives until the host reads it: lrm_workspace_stats and every *_dev entry point check it (the
 // next call after the faulty batch fails), the host-buffer entry points check it per sub-batch.
 #define LRM_ERR_VOTE_OVERFLOW 1u
+// vote tiers (seed_kernels.hip): hits per (read, phase) item up to which one wavefront / one workgroup pass suffices
+#define LRM_VOTE_T1_LIMIT 192
+#define LRM_VOTE_T3_LIMIT 1152
 
 enum LrmKernelId { LRM_K_PACK2BIT = 0, LRM_K_SEED_SEARCH, LRM_K_VOTE, LRM_K_DECIDE,
                    LRM_K_LOCUS, LRM_K_REVCOMP, LRM_K_GACT, LRM_K_PACK_PLANAR, LRM_K_GACT_BS,
                    LRM_K_COUNT };
 #define LRM_MAX_TIMED 4096
 
+#define LRM_WS_SEED 1
+#define LRM_WS_EXTEND 2
 struct lrm_workspace {
     lrm_index *idx;
+    int parts;               // LRM_WS_SEED | LRM_WS_EXTEND: which scratch this workspace owns
     // optional per-kernel timing (HIP events recorded on the launch stream)
     int timing;
     int n_timed;
@@ -181,6 +187,8 @@ void lrm_bs_free_index(lrm_index *idx);
 
 void lrm_set_error(const char *fmt, ...);
 int lrm_require_device(int device);
+int lrm_workspace_create_parts(lrm_workspace **out, lrm_index *idx, uint64_t n_max, uint32_t max_len, uint32_t seed_len,
+                               uint32_t thres, int parts);
 int lrm_ws_take_error(lrm_workspace *ws);        // -2 + message if a kernel raised the workspace's sticky error word
 void lrm_host_ctx_free(lrm_index *idx);          // lrm_host.hip            // hipSetDevice + "no CPU fallback" error
 void lrm_time_begin(lrm_workspace *ws, int kernel, void *stream);

@@ -17,7 +17,6 @@
 #include <cstdlib>
 #include "lrm_internal.h"
 
-#define EMPTY64 0xFFFFFFFFFFFFFFFFull
 
 // A/a=0 C/c=1 G/g=2 T/t=3 ; other bytes are fenced (UB in the reference, lchash.c:38-44)
 __device__ __forceinline__ uint32_t base_code(uint32_t c) { return ((c >> 1) ^ (c >> 2)) & 3u; }
@@ -61,8 +60,7 @@ __global__ __launch_bounds__(256) void pack2bit_kernel(const char *__restrict__ 
 __device__ __forceinline__ uint64_t occ_rank(const LrmIndexView &ix, uint32_t c, uint64_t loc) {
     const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(&ix.occ[loc >> 6].sym[c]);
     const uint32_t r = (uint32_t) loc & 63u;
-    const uint64_t upto = r == 63u ? ~0ull : ((2ull << r) - 1ull);
-    return e.x + (uint64_t) __popcll(e.y & upto);
+    return e.x + (uint64_t) __popcll(e.y & (~0ull >> (63u - r)));
 }
 
 // the two ranks of one backward step; after the table lookup most intervals are a handful of rows,
@@ -73,8 +71,8 @@ __device__ __forceinline__ void occ_rank2(const LrmIndexView &ix, uint32_t c, ui
     ulonglong2 ea = eb;
     if ((loc_a >> 6) != (loc_b >> 6)) ea = *reinterpret_cast<const ulonglong2 *>(&ix.occ[loc_a >> 6].sym[c]);
     const uint32_t qa = (uint32_t) loc_a & 63u, qb = (uint32_t) loc_b & 63u;
-    ra = ea.x + (uint64_t) __popcll(ea.y & (qa == 63u ? ~0ull : ((2ull << qa) - 1ull)));
-    rb = eb.x + (uint64_t) __popcll(eb.y & (qb == 63u ? ~0ull : ((2ull << qb) - 1ull)));
+    ra = ea.x + (uint64_t) __popcll(ea.y & (~0ull >> (63u - qa)));       // bits 0 .. qa
+    rb = eb.x + (uint64_t) __popcll(eb.y & (~0ull >> (63u - qb)));
 }
 
 // SA[row].  Full SA: one 8-byte gather (sa_access, fmidx.c:18-33).  Sampled SA (LRM_SA_SAMPLED=r): only rows
@@ -85,7 +83,13 @@ __device__ __forceinline__ void occ_rank2(const LrmIndexView &ix, uint32_t c, ui
 // (fmidx.c:323, `- 1` on top of the inclusive rank: its walk leaves the text order and gives up after 5*ratio
 // steps); this is the textbook LF, so that the locate equals sa_access on every row -- the two modes of this
 // library give identical results, and csa_access itself is never called on the reference's hot path.
+#ifndef LRM_VOTE_PROBE
+#define LRM_VOTE_PROBE 0          // tuning builds only (tools/build_probe.py): 1 = no SA gather, 2 = no table inserts
+#endif
 __device__ __forceinline__ uint64_t sa_locate(const LrmIndexView &ix, uint64_t row) {
+#if LRM_VOTE_PROBE == 1
+    return row * 977ull;
+#endif
     if (ix.sa_shift == 0) return ix.sa[row];
     const uint64_t rmask = (1ull << ix.sa_shift) - 1ull;
     uint64_t t = 0;
@@ -99,8 +103,7 @@ __device__ __forceinline__ uint64_t sa_locate(const LrmIndexView &ix, uint64_t r
         const ulonglong2 e3 = *reinterpret_cast<const ulonglong2 *>(&b->sym[3]);
         const uint32_t c = (uint32_t) ((e1.y >> r) & 1ull) | ((uint32_t) ((e2.y >> r) & 1ull) << 1) | ((uint32_t) ((e3.y >> r) & 1ull) * 3u);
         const ulonglong2 e = c == 0 ? e0 : c == 1 ? e1 : c == 2 ? e2 : e3;
-        const uint64_t upto = r == 63u ? ~0ull : ((2ull << r) - 1ull);
-        row = ix.c4[c] + e.x + (uint64_t) __popcll(e.y & upto);         // LF(row) = C[c] + rank(c, row)
+        row = ix.c4[c] + e.x + (uint64_t) __popcll(e.y & (~0ull >> (63u - r)));         // LF(row) = C[c] + rank(c, row)
         ++t;
     }
     return ix.sa[row >> ix.sa_shift] + t;
@@ -163,76 +166,6 @@ __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t wi
     return k > l ? 0 : l - k + 1;
 }
 
-// NS seeds per lane searched TOGETHER: the table lookups of all NS seeds are issued before the first is used and
-// every backward step issues the rank gathers of all live seeds before consuming them, so a lane keeps up to NS
-// independent requests in flight instead of one (the kernel is bound by memory latency x resident wavefronts).
-// Same results as NS calls of seed_one; rr[u] = 0 for seeds with act[u] == false.
-template <int NS>
-__device__ __forceinline__ void seed_multi(const LrmIndexView &ix, const uint64_t (&win)[NS], const bool (&act)[NS],
-                                           int seed_len, uint64_t (&k)[NS], uint64_t (&rr)[NS]) {
-    uint64_t l[NS];
-    int left[NS];
-    bool live[NS];
-    const bool use_long = ix.lcl && seed_len >= ix.hl;
-    const int left_long = seed_len - ix.hl, left_ref = seed_len - ix.hlen;
-    uint64_t e[NS];
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {                        // all first-level lookups in flight
-        e[u] = 0;
-        if (act[u]) {
-            if (use_long) e[u] = ix.lcl[(win[u] >> (2 * left_long)) & ((1ull << (2 * ix.hl)) - 1ull)];
-            else if (left_ref >= 0) e[u] = ix.lc[(win[u] >> (2 * left_ref)) & ((1ull << (2 * ix.hlen)) - 1ull)];
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-        k[u] = 0; l[u] = 0; left[u] = 0; live[u] = false; rr[u] = 0;
-        if (!act[u]) continue;
-        if (use_long && (e[u] >> 40) != 0xFFFFFFull) {
-            if (e[u] != 0) { k[u] = e[u] & ((1ull << 40) - 1ull); l[u] = k[u] + (e[u] >> 40) - 1; left[u] = left_long; live[u] = true; }
-        } else if (left_ref >= 0) {
-            // (after a long-table marker the reference's table is read here: rare, intervals >= 2^24-1 rows)
-            lc_lookup(ix, (win[u] >> (2 * left_ref)) & ((1ull << (2 * ix.hlen)) - 1ull), k[u], l[u]);
-            left[u] = left_ref;
-            live[u] = !(k[u] == 0 && l[u] == 0);
-        } else {
-            k[u] = 1; l[u] = ix.length - 1; left[u] = seed_len; live[u] = true;      // seed shorter than hlen (lchash.c:97-99)
-        }
-    }
-    int steps = 0;
-#pragma unroll
-    for (int u = 0; u < NS; ++u) steps = live[u] && left[u] > steps ? left[u] : steps;
-    for (int s = 0; s < steps; ++s) {
-        ulonglong2 ea[NS], eb[NS];
-        uint32_t c[NS];
-        bool go[NS];
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {                    // the rank gathers of every live seed in flight
-            go[u] = live[u] && s < left[u];
-            c[u] = 0; ea[u] = make_ulonglong2(0, 0); eb[u] = ea[u];
-            if (go[u]) {
-                c[u] = (uint32_t) (win[u] >> (2 * (left[u] - 1 - s))) & 3u;
-                const uint64_t la = k[u] - 1, lb = l[u];
-                eb[u] = *reinterpret_cast<const ulonglong2 *>(&ix.occ[lb >> 6].sym[c[u]]);
-                ea[u] = eb[u];
-                if ((la >> 6) != (lb >> 6)) ea[u] = *reinterpret_cast<const ulonglong2 *>(&ix.occ[la >> 6].sym[c[u]]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            if (!go[u]) continue;
-            const uint32_t qa = (uint32_t) (k[u] - 1) & 63u, qb = (uint32_t) l[u] & 63u;
-            const uint64_t ra = ea[u].x + (uint64_t) __popcll(ea[u].y & (qa == 63u ? ~0ull : ((2ull << qa) - 1ull)));
-            const uint64_t rb = eb[u].x + (uint64_t) __popcll(eb[u].y & (qb == 63u ? ~0ull : ((2ull << qb) - 1ull)));
-            k[u] = ix.c4[c[u]] + ra + 1;
-            l[u] = ix.c4[c[u]] + rb;
-            if (k[u] > l[u]) live[u] = false;
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < NS; ++u) rr[u] = (live[u] && k[u] <= l[u]) ? l[u] - k[u] + 1 : 0;
-}
-
 // long table: one lane per hl-mer; the 4^(hl-hlen) extensions of one hlen-mer are contiguous
 __global__ __launch_bounds__(256) void lcl_build_kernel(LrmIndexView ix, int hl, uint64_t *__restrict__ out,
                                                         uint64_t code0) {
@@ -284,9 +217,9 @@ struct __attribute__((aligned(8))) WordPair { uint64_t a, b; };
 
 __device__ __forceinline__ uint64_t read_window(const uint64_t *__restrict__ words, uint32_t j) {
     uint32_t wi = j >> 5, sh = (j & 31) * 2;
-    WordPair w;                                           // one 16-byte request instead of two 8-byte ones
-    __builtin_memcpy(&w, words + wi, sizeof(w));
-    return sh ? ((w.a >> sh) | (w.b << (64 - sh))) : w.a;
+    WordPair w;                                           // ONE 16-byte request; branch-free, so that the compiler
+    __builtin_memcpy(&w, words + wi, sizeof(w));          // cannot split it into a load plus a conditional second load
+    return (w.a >> sh) | ((w.b << 1) << (63 - sh));       // sh == 0: the second term shifts out entirely
 }
 
 // ----------------------------------------------------------------------------------------
@@ -302,7 +235,6 @@ __device__ __forceinline__ uint64_t read_window(const uint64_t *__restrict__ wor
 // (q << tbits) | t, is a property of the hit.
 // ----------------------------------------------------------------------------------------
 #define SS_ITEMS 1024
-template <int MULTI>         // 0: one seed after the other; 2 / 4: that many of the lane's four seeds searched together (seed_multi)
 __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const uint64_t *__restrict__ reads2,
                                                           uint64_t words_per_read,
                                                           const uint32_t *__restrict__ lens,
@@ -326,55 +258,30 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
     __syncthreads();
     // iter fastest: neighbouring seeds overlap, so they share their fate (a sequencing error kills ~20 consecutive
     // seeds, a clean stretch lets all of them run the full backward extension): wavefronts diverge little.
-    // Measured alternatives that lost: q fastest (+26 %), two seeds per lane at once (+26 %), lane refill from a
-    // work chunk (+13 %), packing the survivors of the table lookup into fewer wavefronts (+8 %): the kernel is
-    // bound by the rate of memory requests, not by idle lanes or wavefront slots.
+    // Measured alternatives that lost: q fastest (+26 %), lane refill from a work chunk (+13 %), packing the
+    // survivors of the table lookup into fewer wavefronts (+8 %), and searching 2 / 4 of the lane's seeds TOGETHER
+    // (independent chains per lane, all rank gathers of a step in flight at once: 43.4 / 56.7 ms per step against
+    // 29.0 [r2]): a wavefront of one-seed lanes stops as soon as its 64 neighbouring seeds are dead, a wavefront of
+    // interleaved chains runs until its longest chain ends, and 7.4 G wave-instructions of 64-bit index arithmetic
+    // per Gbp are a third of the kernel's time -- it is not bound by memory latency alone.
     const uint32_t len = lens[read];
     const uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;   // alnmain.c:353 (fenced for len<s)
     const uint64_t *words = reads2 + read * words_per_read;
-    if (MULTI) {
-        constexpr int NS = MULTI > 0 ? MULTI : 1;
 #pragma unroll 1
-      for (int grp = 0; grp < SS_ITEMS / 256 / NS; ++grp) {
-        uint64_t win[NS], k[NS], rr[NS];
-        uint32_t qs[NS], phs[NS];
-        bool act[NS];
-#pragma unroll
-        for (int it = 0; it < NS; ++it) {
-            const uint32_t item = chunk * SS_ITEMS + (uint32_t) (grp * NS + it) * 256 + tid;
-            qs[it] = item / np; phs[it] = item % np;
-            const uint64_t j = (uint64_t) (phase_lo + (int) phs[it]) + (uint64_t) qs[it] * (uint64_t) P;
-            act[it] = qs[it] < cap_q && j < jl;
-            win[it] = act[it] ? read_window(words, (uint32_t) j) : 0ull;
-        }
-        seed_multi<NS>(ix, win, act, seed_len, k, rr);
-#pragma unroll
-        for (int it = 0; it < NS; ++it) {
-            if (rr[it] > 0 && rr[it] < (uint64_t) thres) {
-                const uint32_t slot = atomicAdd(&s_cnt[phs[it]], 1u);
-                atomicAdd(&s_hits[phs[it]], (uint32_t) rr[it]);
-                s_rec[phs[it] * cap_pp + slot] = k[it] | (rr[it] << 40);
-                s_q[phs[it] * cap_pp + slot] = qs[it];
-            }
-        }
-      }
-    } else {
-#pragma unroll 1
-        for (uint32_t it = 0; it < SS_ITEMS / 256; ++it) {
-            const uint32_t item = chunk * SS_ITEMS + it * 256 + tid;
-            const uint32_t q = item / np, ph = item % np;
-            if (q >= cap_q) break;
-            const uint64_t j = (uint64_t) (phase_lo + (int) ph) + (uint64_t) q * (uint64_t) P;
-            if (j >= jl) continue;
-            const uint64_t win = read_window(words, (uint32_t) j);
-            uint64_t k, l;
-            const uint64_t rr = seed_one(ix, win, seed_len, k, l);
-            if (rr > 0 && rr < (uint64_t) thres) {
-                const uint32_t slot = atomicAdd(&s_cnt[ph], 1u);
-                atomicAdd(&s_hits[ph], (uint32_t) rr);
-                s_rec[ph * cap_pp + slot] = k | (rr << 40);
-                s_q[ph * cap_pp + slot] = q;
-            }
+    for (uint32_t it = 0; it < SS_ITEMS / 256; ++it) {
+        const uint32_t item = chunk * SS_ITEMS + it * 256 + tid;
+        const uint32_t q = item / np, ph = item % np;
+        if (q >= cap_q) break;
+        const uint32_t j = (uint32_t) phase_lo + ph + q * (uint32_t) P;        // < 2^32: cap_q * P <= max_len + P
+        if (j >= jl) continue;
+        const uint64_t win = read_window(words, j);
+        uint64_t k, l;
+        const uint64_t rr = seed_one(ix, win, seed_len, k, l);
+        if (rr > 0 && rr < (uint64_t) thres) {
+            const uint32_t slot = atomicAdd(&s_cnt[ph], 1u);
+            atomicAdd(&s_hits[ph], (uint32_t) rr);
+            s_rec[ph * cap_pp + slot] = k | (rr << 40);
+            s_q[ph * cap_pp + slot] = q;
         }
     }
     __syncthreads();
@@ -440,38 +347,55 @@ __global__ __launch_bounds__(256) void seed_search_debug_kernel(LrmIndexView ix,
 #define VG 16                // items per workgroup (default; LRM_VOTE_VG)
 #define VG_MAX 64
 #define T1_SLOTS 256
-#define T1_LIMIT 192
-#define T3_SLOTS 1280
-#define T3_LIMIT 960
+#define T1_LIMIT LRM_VOTE_T1_LIMIT
+#define T3_SLOTS 1536
+#define T3_LIMIT LRM_VOTE_T3_LIMIT
 #define T3_CHUNK 512            // survivors per prefix chunk of the workgroup tier (2 per thread)
 #define EMPTY32 0xFFFFFFFFu
 
+// never a vote key: keys are SA - j (u64 wrap) with SA < 2^40 and j < 2^32, i.e. in [0, 2^40) or [2^64 - 2^32, 2^64)
+#define EMPTY_KEY 0x8000000000000000ull
+
 __device__ __forceinline__ uint32_t bucket_hash(uint64_t bucket) {
-    return (uint32_t) ((bucket * 0x9E3779B97F4A7C15ull) >> 32);
+    uint32_t x = (uint32_t) bucket ^ (uint32_t) (bucket >> 29);
+    x *= 0x9E3779B1u;
+    x ^= x >> 15;
+    return x * 0x85EBCA6Bu;
 }
 
+// One slot = {min key of the bucket, count, min order key}: the bucket is key >> 4 (histo.c:26-28) and the entry's
+// key is the minimum key added to it (histo.c:45-49), so the smallest key IS the slot's identity and its payload.
 struct VoteTable {
-    uint64_t *bucket;
-    uint32_t *count, *first, *minlow;
+    uint64_t *key;
+    uint32_t *count, *first;
     uint32_t slots;
 };
 
 // Returns false only if the table is full (never in the wavefront tier, where H <= 0.75*slots; in the multi-pass
 // tier only under a pathological hash skew) -- the probe loop is bounded so a wave can never spin.
-__device__ __forceinline__ bool vote_insert(const VoteTable &t, uint64_t key, uint32_t h, uint32_t hash) {
-    const uint64_t bucket = key >> 4;                                   // histo.c:26-28
+__device__ __forceinline__ bool vote_insert(const VoteTable &t, uint64_t key, uint32_t order, uint32_t hash) {
+    const uint64_t bucket = key >> 4;
     uint32_t slot = (uint32_t) (((uint64_t) hash * t.slots) >> 32);
     for (uint32_t probe = 0; probe < t.slots; ++probe) {
-        unsigned long long prev = atomicCAS((unsigned long long *) &t.bucket[slot], EMPTY64, bucket);
-        if (prev == EMPTY64 || prev == bucket) {
+        const unsigned long long prev = atomicCAS((unsigned long long *) &t.key[slot], EMPTY_KEY, key);
+        if (prev == EMPTY_KEY || (prev >> 4) == bucket) {
+            if (prev != EMPTY_KEY && key < prev) atomicMin((unsigned long long *) &t.key[slot], (unsigned long long) key);
             atomicAdd(&t.count[slot], 1u);
-            atomicMin(&t.minlow[slot], (uint32_t) (key & 15));
-            atomicMin(&t.first[slot], h);
+            atomicMin(&t.first[slot], order);
             return true;
         }
         slot = slot + 1 == t.slots ? 0 : slot + 1;
     }
     return false;
+}
+
+__device__ __forceinline__ bool vote_admit(const VoteTable &t, uint64_t key, uint32_t order, uint32_t passes, uint32_t pass) {
+#if LRM_VOTE_PROBE == 2
+    return key != 0x123456789ull;
+#endif
+    const uint32_t hash = bucket_hash(key >> 4);
+    if (passes == 1 || (hash >> 16) % passes == pass) return vote_insert(t, key, order, hash);
+    return true;
 }
 
 struct PhaseTop { uint64_t key1, bucket1, key2, bucket2; uint32_t val1, first1, val2, first2; };
@@ -485,8 +409,7 @@ __device__ __forceinline__ void write_phase(LrmPhaseRes *out, const PhaseTop &p)
 
 // inclusive prefix sum over the 64 lanes on the DPP network: four row shifts inside the rows of 16, then the
 // row totals are broadcast to the following rows (row_bcast:15 / row_bcast:31) -- six v_add_u32_dpp, no LDS
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-    (void) lane;
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false);      // row_shr:1
     v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false);      // row_shr:2
     v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false);      // row_shr:4
@@ -494,6 +417,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
     v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
     v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
     return v;
+}
+
+// # of set bits of a wave mask below this lane
+__device__ __forceinline__ uint32_t mask_rank(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
 }
 
 // Top-2 of a vote table, "count descending, first-seen ascending" (histo.c:84-96 with the insertion order carried
@@ -539,8 +467,8 @@ __device__ __forceinline__ Top2 table_top2(const VoteTable &t, uint32_t tid) {
     return r;
 }
 
-// survivor s of the hit h: off[s] <= h < off[s + 1]  (off: exclusive prefix of the survivors' hit counts, strictly
-// increasing because every survivor has at least one hit; cnt >= 1)
+// survivor s of the hit h: off[s] <= h < off[s + 1]  (off: exclusive prefix of the staged survivors' hit counts,
+// strictly increasing because every survivor has at least one hit; cnt >= 1)
 __device__ __forceinline__ uint32_t find_seed(const uint32_t *off, uint32_t cnt, uint32_t h) {
     uint32_t lo = 0, hi = cnt;
     while (hi - lo > 1) {
@@ -550,8 +478,11 @@ __device__ __forceinline__ uint32_t find_seed(const uint32_t *off, uint32_t cnt,
     return lo;
 }
 
-
-// The hits [0, total) of the survivors staged in LDS (off / srec / sq), voted by NT threads (tid of NT).
+// Survivors come in two kinds.  UNIQUE seeds (rr == 1: the read's true locus, ~3/4 of the survivors of a noisy
+// read) are voted by the lane that loaded them: one SA gather, no staging.  REPEAT seeds (rr > 1) are compacted
+// into LDS with the prefix sums of their hit counts and their hits are expanded flat: hit h finds its seed by a
+// binary search over the (few) staged repeat seeds.
+// The hits [0, total) of the staged survivors (off / srec / sq), voted by NT threads (tid of NT).
 template <int NT, int VOTE_U>               // VOTE_U: SA gathers in flight per lane
 __device__ __forceinline__ bool vote_hits(const LrmIndexView &ix, const VoteTable &t, const uint32_t *off,
                                           const uint64_t *srec, const uint32_t *sq, uint32_t cnt, uint32_t total,
@@ -577,9 +508,8 @@ __device__ __forceinline__ bool vote_hits(const LrmIndexView &ix, const VoteTabl
             const uint32_t h = hb + (uint32_t) u * NT + tid;
             if (h < total) {
                 const uint32_t q = sq[ss[u]];
-                const uint64_t key = v[u] - ((uint64_t) iter + (uint64_t) q * (uint64_t) P);   // alnmain.c:363-365 (u64 wrap kept)
-                const uint32_t hash = bucket_hash(key >> 4);
-                if (passes == 1 || hash % passes == pass) ok &= vote_insert(t, key, (q << tbits) | tt[u], hash);
+                const uint64_t key = v[u] - (uint64_t) (iter + q * P);              // alnmain.c:363-365 (u64 wrap kept); j < 2^32
+                ok &= vote_admit(t, key, (q << tbits) | tt[u], passes, pass);
             }
         }
     }
@@ -588,49 +518,63 @@ __device__ __forceinline__ bool vote_hits(const LrmIndexView &ix, const VoteTabl
 
 // ---- wavefront tier: H <= T1_LIMIT, so at most T1_LIMIT survivors -------------------------------------------
 struct WaveLds {
-    uint64_t bucket[T1_SLOTS];
-    uint64_t srec[T1_LIMIT];
-    uint32_t count[T1_SLOTS], first[T1_SLOTS], minlow[T1_SLOTS];
-    uint32_t off[T1_LIMIT + 4];
-    uint32_t sq[T1_LIMIT];
+    uint64_t key[T1_SLOTS];
+    uint64_t srec[T1_LIMIT / 2];             // repeat seeds have >= 2 hits each
+    uint32_t count[T1_SLOTS], first[T1_SLOTS];
+    uint32_t off[T1_LIMIT / 2 + 4];
+    uint32_t sq[T1_LIMIT / 2];
 };
 
 template <int VOTE_U>
 __device__ __forceinline__ void vote_item_wave(const LrmIndexView &ix, const uint64_t *__restrict__ rec,
                                                const uint32_t *__restrict__ recq, uint32_t cnt, uint32_t H,
                                                uint32_t iter, uint32_t P, uint32_t tbits, int lane, WaveLds &L,
-                                               LrmPhaseRes *out) {
-    VoteTable t = {L.bucket, L.count, L.first, L.minlow, 0};
+                                               LrmPhaseRes *out, uint32_t load) {
+    VoteTable t = {L.key, L.count, L.first, 0};
     {   // clear / scan only as much of the table as this item can fill (<= 75 % load)
-        const uint32_t eff = H + H / 3 + 64;
+        const uint32_t eff = H * 100u / load + 64;
         t.slots = eff < (uint32_t) T1_SLOTS ? eff : (uint32_t) T1_SLOTS;
     }
-    for (uint32_t s = lane; s < t.slots; s += 64) {
-        t.bucket[s] = EMPTY64; t.count[s] = 0; t.first[s] = EMPTY32; t.minlow[s] = EMPTY32;
-    }
-    uint32_t run = 0;
+    constexpr int NU = (T1_LIMIT + 63) / 64;
+    uint64_t e[NU], sv[NU];
+    uint32_t qq[NU];
 #pragma unroll
-    for (int u = 0; u < (T1_LIMIT + 63) / 64; ++u) {
+    for (int u = 0; u < NU; ++u) {                                   // survivor loads first, table clear behind them
         const uint32_t s = (uint32_t) u * 64 + (uint32_t) lane;
-        const uint64_t e = s < cnt ? rec[s] : 0ull;
-        const uint32_t qq = s < cnt ? recq[s] : 0u;
-        const uint32_t rr = (uint32_t) (e >> 40);
-        const uint32_t incl = wave_incl_scan(rr, lane);
-        if (s < cnt) { L.off[s] = run + incl - rr; L.srec[s] = e; L.sq[s] = qq; }
-        run += (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+        e[u] = s < cnt ? rec[s] : 0ull;
+        qq[u] = s < cnt ? recq[s] : 0u;
     }
-    if (lane == 0) L.off[cnt] = run;
+    for (uint32_t s = lane; s < t.slots; s += 64) { t.key[s] = EMPTY_KEY; t.count[s] = 0; t.first[s] = EMPTY32; }
+    uint32_t run = 0, nbig = 0;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const uint32_t rr = (uint32_t) (e[u] >> 40);
+        sv[u] = rr == 1 ? sa_locate(ix, e[u] & ((1ull << 40) - 1ull)) : 0ull;       // unique seeds: gather at once
+        const bool big = rr > 1;
+        const unsigned long long bm = __ballot(big);
+        const uint32_t incl = wave_incl_scan(big ? rr : 0u);
+        if (big) {
+            const uint32_t idx = nbig + mask_rank(bm);
+            L.off[idx] = run + incl - rr; L.srec[idx] = e[u]; L.sq[idx] = qq[u];
+        }
+        run += (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+        nbig += (uint32_t) __popcll(bm);
+    }
+    if (lane == 0) L.off[nbig] = run;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    vote_hits<64, VOTE_U>(ix, t, L.off, L.srec, L.sq, cnt, run, iter, P, tbits, (uint32_t) lane, 1u, 0u);
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+        if ((uint32_t) (e[u] >> 40) == 1) vote_admit(t, sv[u] - (uint64_t) (iter + qq[u] * P), qq[u] << tbits, 1u, 0u);
+    if (nbig) vote_hits<64, VOTE_U>(ix, t, L.off, L.srec, L.sq, nbig, run, iter, P, tbits, (uint32_t) lane, 1u, 0u);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     const Top2 w = table_top2<64>(t, (uint32_t) lane);
     if (lane == 0) {
         PhaseTop p = {};
-        if (w.k1) { p.val1 = (uint32_t) (w.k1 >> 32); p.bucket1 = t.bucket[w.s1]; p.key1 = (p.bucket1 << 4) | t.minlow[w.s1]; }
-        if (w.k2) { p.val2 = (uint32_t) (w.k2 >> 32); p.bucket2 = t.bucket[w.s2]; p.key2 = (p.bucket2 << 4) | t.minlow[w.s2]; }
+        if (w.k1) { p.val1 = (uint32_t) (w.k1 >> 32); p.key1 = t.key[w.s1]; p.bucket1 = p.key1 >> 4; }
+        if (w.k2) { p.val2 = (uint32_t) (w.k2 >> 32); p.key2 = t.key[w.s2]; p.bucket2 = p.key2 >> 4; }
         write_phase(out, p);
     }
     __builtin_amdgcn_wave_barrier();
@@ -638,9 +582,9 @@ __device__ __forceinline__ void vote_item_wave(const LrmIndexView &ix, const uin
 
 // ---- workgroup tier -------------------------------------------------------------------------------------------
 struct BlockLds {
-    uint64_t bucket[T3_SLOTS];
+    uint64_t key[T3_SLOTS];
     uint64_t srec[T3_CHUNK];
-    uint32_t count[T3_SLOTS], first[T3_SLOTS], minlow[T3_SLOTS];
+    uint32_t count[T3_SLOTS], first[T3_SLOTS];
     uint32_t off[T3_CHUNK + 4];
     uint32_t sq[T3_CHUNK];
 };
@@ -651,42 +595,50 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
                                                 const uint32_t *__restrict__ recq, uint32_t cnt, uint32_t H,
                                                 uint32_t iter, uint32_t P, uint32_t tbits, uint32_t slots, uint32_t limit,
                                                 BlockLds &L, uint32_t *s_wsum, Top2 *s_top, LrmPhaseRes *out,
-                                                uint32_t *err_word) {
+                                                uint32_t *err_word, uint32_t load) {
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     const int lane = (int) (tid & 63);
-    VoteTable t = {L.bucket, L.count, L.first, L.minlow, slots};
+    VoteTable t = {L.key, L.count, L.first, slots};
     const uint32_t passes = (H + limit - 1) / limit;
     {
         const uint32_t per_pass = passes > 1 ? limit : H;
-        const uint32_t eff = per_pass + per_pass / 3 + 64;
+        const uint32_t eff = per_pass * 100u / load + 64;
         t.slots = eff < slots ? eff : slots;
     }
     PhaseTop best = {};
     for (uint32_t pass = 0; pass < passes; ++pass) {
-        for (uint32_t s = tid; s < t.slots; s += 256) {
-            t.bucket[s] = EMPTY64; t.count[s] = 0; t.first[s] = EMPTY32; t.minlow[s] = EMPTY32;
-        }
+        for (uint32_t s = tid; s < t.slots; s += 256) { t.key[s] = EMPTY_KEY; t.count[s] = 0; t.first[s] = EMPTY32; }
         bool ok = true;
         for (uint32_t c0 = 0; c0 < cnt; c0 += T3_CHUNK) {
             const uint32_t nc = cnt - c0 < (uint32_t) T3_CHUNK ? cnt - c0 : (uint32_t) T3_CHUNK;
-            // two consecutive survivors per thread, one block scan of the per-thread sums
+            // two consecutive survivors per thread; unique seeds gather at once, repeat seeds are compacted into LDS
             const uint32_t s0 = 2 * tid, s1 = s0 + 1;
             const uint64_t e0 = s0 < nc ? rec[c0 + s0] : 0ull, e1 = s1 < nc ? rec[c0 + s1] : 0ull;
             const uint32_t q0 = s0 < nc ? recq[c0 + s0] : 0u, q1 = s1 < nc ? recq[c0 + s1] : 0u;
             const uint32_t r0 = (uint32_t) (e0 >> 40), r1 = (uint32_t) (e1 >> 40);
-            const uint32_t incl = wave_incl_scan(r0 + r1, lane);
+            const uint64_t v0 = r0 == 1 ? sa_locate(ix, e0 & ((1ull << 40) - 1ull)) : 0ull;
+            const uint64_t v1 = r1 == 1 ? sa_locate(ix, e1 & ((1ull << 40) - 1ull)) : 0ull;
+            const uint32_t b0 = r0 > 1 ? 1u : 0u, b1 = r1 > 1 ? 1u : 0u;
+            const uint32_t h0 = b0 ? r0 : 0u, h1 = b1 ? r1 : 0u;
+            const uint32_t incl_h = wave_incl_scan(h0 + h1), incl_n = wave_incl_scan(b0 + b1);
             __syncthreads();                                   // the previous chunk's (or pass's) staging is no longer read
-            if (lane == 63) s_wsum[wave] = incl;
+            if (lane == 63) { s_wsum[wave] = incl_h; s_wsum[4 + wave] = incl_n; }
             __syncthreads();
-            uint32_t woff = 0, total = 0;
+            uint32_t woff_h = 0, total = 0, woff_n = 0, nbig = 0;
 #pragma unroll
-            for (uint32_t w = 0; w < 4; ++w) { const uint32_t x = s_wsum[w]; total += x; if (w < wave) woff += x; }
-            const uint32_t excl = woff + incl - (r0 + r1);
-            if (s0 < nc) { L.off[s0] = excl; L.srec[s0] = e0; L.sq[s0] = q0; }
-            if (s1 < nc) { L.off[s1] = excl + r0; L.srec[s1] = e1; L.sq[s1] = q1; }
-            if (tid == 0) L.off[nc] = total;
+            for (uint32_t w = 0; w < 4; ++w) {
+                const uint32_t x = s_wsum[w], y = s_wsum[4 + w];
+                total += x; nbig += y;
+                if (w < wave) { woff_h += x; woff_n += y; }
+            }
+            const uint32_t excl_h = woff_h + incl_h - (h0 + h1), excl_n = woff_n + incl_n - (b0 + b1);
+            if (b0) { L.off[excl_n] = excl_h; L.srec[excl_n] = e0; L.sq[excl_n] = q0; }
+            if (b1) { L.off[excl_n + b0] = excl_h + h0; L.srec[excl_n + b0] = e1; L.sq[excl_n + b0] = q1; }
+            if (tid == 0) L.off[nbig] = total;
             __syncthreads();
-            ok &= vote_hits<256, VOTE_U>(ix, t, L.off, L.srec, L.sq, nc, total, iter, P, tbits, tid, passes, pass);
+            if (r0 == 1) ok &= vote_admit(t, v0 - (uint64_t) (iter + q0 * P), q0 << tbits, passes, pass);
+            if (r1 == 1) ok &= vote_admit(t, v1 - (uint64_t) (iter + q1 * P), q1 << tbits, passes, pass);
+            if (nbig) ok &= vote_hits<256, VOTE_U>(ix, t, L.off, L.srec, L.sq, nbig, total, iter, P, tbits, tid, passes, pass);
         }
         if (!ok) *(volatile uint32_t *) err_word = LRM_ERR_VOTE_OVERFLOW;   // host-coherent, sticky
         __syncthreads();
@@ -707,19 +659,19 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
                     else if (ks[y] > ck[1]) { ck[1] = ks[y]; cslot[1] = ss[y]; }
                 }
             }
-            uint64_t r1 = best.val1 ? ((uint64_t) best.val1 << 32) | (0xFFFFFFFFu - best.first1) : 0;
-            uint64_t r2 = best.val2 ? ((uint64_t) best.val2 << 32) | (0xFFFFFFFFu - best.first2) : 0;
+            uint64_t r1k = best.val1 ? ((uint64_t) best.val1 << 32) | (0xFFFFFFFFu - best.first1) : 0;
+            uint64_t r2k = best.val2 ? ((uint64_t) best.val2 << 32) | (0xFFFFFFFFu - best.first2) : 0;
             PhaseTop nb = best;
             for (int x = 0; x < 2; ++x) {
                 const uint64_t c = ck[x];
                 if (!c) continue;
                 const uint32_t cv = (uint32_t) (c >> 32), cf = 0xFFFFFFFFu - (uint32_t) c;
-                const uint64_t bk = t.bucket[cslot[x]], ky = (bk << 4) | t.minlow[cslot[x]];
-                if (c > r1) {
-                    nb.key2 = nb.key1; nb.bucket2 = nb.bucket1; nb.val2 = nb.val1; nb.first2 = nb.first1; r2 = r1;
-                    nb.key1 = ky; nb.bucket1 = bk; nb.val1 = cv; nb.first1 = cf; r1 = c;
-                } else if (c > r2) {
-                    nb.key2 = ky; nb.bucket2 = bk; nb.val2 = cv; nb.first2 = cf; r2 = c;
+                const uint64_t ky = t.key[cslot[x]], bk = ky >> 4;
+                if (c > r1k) {
+                    nb.key2 = nb.key1; nb.bucket2 = nb.bucket1; nb.val2 = nb.val1; nb.first2 = nb.first1; r2k = r1k;
+                    nb.key1 = ky; nb.bucket1 = bk; nb.val1 = cv; nb.first1 = cf; r1k = c;
+                } else if (c > r2k) {
+                    nb.key2 = ky; nb.bucket2 = bk; nb.val2 = cv; nb.first2 = cf; r2k = c;
                 }
             }
             best = nb;
@@ -736,12 +688,12 @@ __global__ __launch_bounds__(256) void vote_kernel(LrmIndexView ix, const uint64
                                                    const uint32_t *__restrict__ ghits,
                                                    const uint8_t *__restrict__ decided, uint64_t n, int seed_len,
                                                    int phase_lo, int phase_hi, uint32_t cap_q, uint32_t tbits,
-                                                   uint32_t slots3, uint32_t limit3, uint32_t vg, uint32_t limit1,
+                                                   uint32_t slots3, uint32_t limit3, uint32_t vg, uint32_t limit1, uint32_t load,
                                                    LrmPhaseRes *__restrict__ phase_res, uint32_t *err_word) {
     __shared__ VoteLds lds;
     __shared__ uint32_t g_H[VG_MAX], g_cnt[VG_MAX];
     __shared__ uint64_t g_id[VG_MAX];
-    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_wsum[8];
     __shared__ Top2 s_top[4];
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     const int lane = (int) (tid & 63);
@@ -769,7 +721,7 @@ __global__ __launch_bounds__(256) void vote_kernel(LrmIndexView ix, const uint64
         if (H == 0 || H > limit1) continue;
         const uint64_t id = g_id[g];
         vote_item_wave<VOTE_U>(ix, rec + id * cap_q, recq + id * cap_q, g_cnt[g], H, (uint32_t) (id % P), P, tbits, lane,
-                       lds.w[wave], &phase_res[id]);
+                       lds.w[wave], &phase_res[id], load);
     }
     __syncthreads();
     for (uint32_t g = 0; g < vg; ++g) {                       // workgroup tier: one item after the other
@@ -777,7 +729,7 @@ __global__ __launch_bounds__(256) void vote_kernel(LrmIndexView ix, const uint64
         if (H <= limit1) continue;
         const uint64_t id = g_id[g];
         vote_item_block<VOTE_U>(ix, rec + id * cap_q, recq + id * cap_q, g_cnt[g], H, (uint32_t) (id % P), P, tbits, slots3,
-                        limit3, lds.b, s_wsum, s_top, &phase_res[id], err_word);
+                        limit3, lds.b, s_wsum, s_top, &phase_res[id], err_word, load);
         __syncthreads();
     }
 }
@@ -900,8 +852,9 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
     if (const char *e = getenv("LRM_VOTE_VG")) { const int v = atoi(e); if (v >= 1 && v <= VG_MAX) vg = (uint32_t) v; }
     if (const char *e = getenv("LRM_VOTE_T1")) { const int v = atoi(e); if (v >= 0 && v <= T1_LIMIT) t1_limit = (uint32_t) v; }
     if (const char *e = getenv("LRM_VOTE_U")) vote_u = atoi(e);
-    int ss_multi = 4;
-    if (const char *e = getenv("LRM_SS_MULTI")) ss_multi = atoi(e);
+    uint32_t vote_load = 50;        // percent of the table slots an item is sized for (when the table allows): at 75 % the
+                                    // linear probes of the slowest lane cost +1.7 ms per Gbp [r2], at 90 % +4.4 ms
+    if (const char *e = getenv("LRM_VOTE_LOAD")) { const int v = atoi(e); if (v >= 10 && v <= 95) vote_load = (uint32_t) v; }
     for (int round = 0; round < 2; ++round) {
         int lo = round == 0 ? 0 : 1;
         int hi = round == 0 ? 0 : P - 1;
@@ -912,8 +865,7 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
         uint64_t blocks = n * bpr;
         if (blocks > 0x7fffffffull) { lrm_set_error("seed_search grid too large: split the batch"); return -1; }
         lrm_time_begin(ws, LRM_K_SEED_SEARCH, stream);
-        auto sk = ss_multi == 4 ? seed_search_kernel<4> : ss_multi == 2 ? seed_search_kernel<2> : seed_search_kernel<0>;
-        hipLaunchKernelGGL(sk, dim3((uint32_t) blocks), dim3(256), 0, stream, idx->view,
+        hipLaunchKernelGGL(seed_search_kernel, dim3((uint32_t) blocks), dim3(256), 0, stream, idx->view,
                            ws->d_reads2, wpr, d_lens, dec, n, (int) seed_len, thres, lo, hi, cap_q, bpr,
                            ws->d_rec, ws->d_recq, ws->d_cnt, ws->d_hcount);
         lrm_time_end(ws, stream);
@@ -924,7 +876,7 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
         auto vk = vote_u == 2 ? vote_kernel<2> : vote_u == 8 ? vote_kernel<8> : vote_kernel<4>;
         hipLaunchKernelGGL(vk, dim3((uint32_t) vblocks), dim3(256), 0, stream, idx->view, ws->d_rec, ws->d_recq,
                            ws->d_cnt, ws->d_hcount, dec, n, (int) seed_len, lo, hi, cap_q, tbits, t3_slots, t3_limit,
-                           vg, t1_limit, ws->d_phase, ws->d_err);
+                           vg, t1_limit, vote_load, ws->d_phase, ws->d_err);
         lrm_time_end(ws, stream);
         lrm_time_begin(ws, LRM_K_DECIDE, stream);
         hipLaunchKernelGGL(decide_kernel, dim3((uint32_t) ((n + 255) / 256)), dim3(256), 0, stream, ws->d_phase,

@@ -208,3 +208,11 @@ def test_suffix_array_values_beyond_32_bits(gpu):
         assert np.array_equal(got, want)
     finally:
         di.close()
+
+
+def test_rccl_is_loadable_and_bound(gpu):
+    """The multi-device index broadcast goes through RCCL (dlopen'ed: librccl.so.1); a one-GPU box cannot run it,
+    so the same code is driven on a 1-rank communicator: library load, ncclCommInitAll, grouped ncclBroadcast in
+    256 MiB pieces, ncclCommDestroy."""
+    rc = capi.lib.lrm_debug_rccl_selftest(gpu, (300 << 20) + 12345)
+    assert rc == 0, (rc, capi.lib.lrm_last_error())
