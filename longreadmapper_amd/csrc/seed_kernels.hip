@@ -75,6 +75,14 @@ __device__ __forceinline__ void occ_rank2(const LrmIndexView &ix, uint32_t c, ui
     rb = eb.x + (uint64_t) __popcll(eb.y & (~0ull >> (63u - qb)));
 }
 
+// C[c] (fmidx.c:101-125) from the by-value view: a select over four scalar registers.  Indexing the array with the
+// lane's symbol made the compiler fetch it from the kernel-argument segment with a vector load -- one more memory
+// request in every backward step of a kernel that is bound by the number of requests.
+__device__ __forceinline__ uint64_t c4_of(const LrmIndexView &ix, uint32_t c) {
+    const uint64_t lo = (c & 1u) ? ix.c4[1] : ix.c4[0], hi = (c & 1u) ? ix.c4[3] : ix.c4[2];
+    return (c & 2u) ? hi : lo;
+}
+
 // SA[row].  Full SA: one 8-byte gather (sa_access, fmidx.c:18-33).  Sampled SA (LRM_SA_SAMPLED=r): only rows
 // i*r are stored -- the reference's csa table (fmidx.c:153-163) -- and the other rows walk LF steps until
 // they reach a stored row or the '$' row: SA[row] = SA[LF^t(row)] + t (csa_access, fmidx.c:315-331).  The
@@ -84,7 +92,8 @@ __device__ __forceinline__ void occ_rank2(const LrmIndexView &ix, uint32_t c, ui
 // steps); this is the textbook LF, so that the locate equals sa_access on every row -- the two modes of this
 // library give identical results, and csa_access itself is never called on the reference's hot path.
 #ifndef LRM_VOTE_PROBE
-#define LRM_VOTE_PROBE 0          // tuning builds only (tools/build_probe.py): 1 = no SA gather, 2 = no table inserts
+#define LRM_VOTE_PROBE 0          // tuning builds only (tools/build_probe.py): 1 = no SA gather, 2 = no table inserts,
+                                  // 4 = slot claims only
 #endif
 __device__ __forceinline__ uint64_t sa_locate(const LrmIndexView &ix, uint64_t row) {
 #if LRM_VOTE_PROBE == 1
@@ -103,7 +112,7 @@ __device__ __forceinline__ uint64_t sa_locate(const LrmIndexView &ix, uint64_t r
         const ulonglong2 e3 = *reinterpret_cast<const ulonglong2 *>(&b->sym[3]);
         const uint32_t c = (uint32_t) ((e1.y >> r) & 1ull) | ((uint32_t) ((e2.y >> r) & 1ull) << 1) | ((uint32_t) ((e3.y >> r) & 1ull) * 3u);
         const ulonglong2 e = c == 0 ? e0 : c == 1 ? e1 : c == 2 ? e2 : e3;
-        row = ix.c4[c] + e.x + (uint64_t) __popcll(e.y & (~0ull >> (63u - r)));         // LF(row) = C[c] + rank(c, row)
+        row = c4_of(ix, c) + e.x + (uint64_t) __popcll(e.y & (~0ull >> (63u - r)));         // LF(row) = C[c] + rank(c, row)
         ++t;
     }
     return ix.sa[row >> ix.sa_shift] + t;
@@ -159,8 +168,9 @@ __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t wi
         uint32_t c = (uint32_t) (win >> (2 * i)) & 3u;
         uint64_t ra, rb;
         occ_rank2(ix, c, k - 1, l, ra, rb);
-        k = ix.c4[c] + ra + 1;
-        l = ix.c4[c] + rb;
+        const uint64_t cc = c4_of(ix, c);
+        k = cc + ra + 1;
+        l = cc + rb;
         if (k > l) break;
     }
     return k > l ? 0 : l - k + 1;
@@ -180,8 +190,9 @@ __global__ __launch_bounds__(256) void lcl_build_kernel(LrmIndexView ix, int hl,
             const uint32_t c = (uint32_t) (code >> (2 * i)) & 3u;
             uint64_t ra, rb;
             occ_rank2(ix, c, k - 1, l, ra, rb);
-            k = ix.c4[c] + ra + 1;
-            l = ix.c4[c] + rb;
+            const uint64_t cc = c4_of(ix, c);
+            k = cc + ra + 1;
+            l = cc + rb;
         }
         if (k <= l) {
             const uint64_t cnt = l - k + 1;
@@ -373,15 +384,19 @@ struct VoteTable {
 
 // Returns false only if the table is full (never in the wavefront tier, where H <= 0.75*slots; in the multi-pass
 // tier only under a pathological hash skew) -- the probe loop is bounded so a wave can never spin.
-__device__ __forceinline__ bool vote_insert(const VoteTable &t, uint64_t key, uint32_t order, uint32_t hash) {
+__device__ __forceinline__ bool vote_insert(const VoteTable &t, uint64_t key, uint32_t order, uint32_t hash, uint32_t n = 1u) {
     const uint64_t bucket = key >> 4;
     uint32_t slot = (uint32_t) (((uint64_t) hash * t.slots) >> 32);
     for (uint32_t probe = 0; probe < t.slots; ++probe) {
+        // (a plain read before the compare-and-swap, to step over occupied slots cheaply, measured SLOWER: 15.5 vs
+        //  13.4 ms per Gbp [r2] -- the extra dependent LDS round trip costs more than the CAS it saves)
         const unsigned long long prev = atomicCAS((unsigned long long *) &t.key[slot], EMPTY_KEY, key);
         if (prev == EMPTY_KEY || (prev >> 4) == bucket) {
+#if LRM_VOTE_PROBE != 4          // (tuning build 4: the slot claim alone)
             if (prev != EMPTY_KEY && key < prev) atomicMin((unsigned long long *) &t.key[slot], (unsigned long long) key);
-            atomicAdd(&t.count[slot], 1u);
+            atomicAdd(&t.count[slot], n);
             atomicMin(&t.first[slot], order);
+#endif
             return true;
         }
         slot = slot + 1 == t.slots ? 0 : slot + 1;
@@ -563,6 +578,8 @@ __device__ __forceinline__ void vote_item_wave(const LrmIndexView &ix, const uin
     if (lane == 0) L.off[nbig] = run;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // (peeling the most frequent buckets of a batch off with ballots + wave reductions, so that one lane adds a whole
+    //  group of equal votes, measured SLOWER: 18.8 vs 13.4 ms per Gbp [r2] -- same-slot contention is not the cost)
 #pragma unroll
     for (int u = 0; u < NU; ++u)
         if ((uint32_t) (e[u] >> 40) == 1) vote_admit(t, sv[u] - (uint64_t) (iter + qq[u] * P), qq[u] << tbits, 1u, 0u);
