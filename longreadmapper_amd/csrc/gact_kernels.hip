@@ -4,8 +4,11 @@
 //
 //   locus_resolve  one lane per read: seq_lookup with the reference's u64 arithmetic
 //   revcomp        reverse-complement reads that resolved to the reverse strand, in place
-//   gact           ONE WAVEFRONT PER READ; tiles of the read are walked in sequence
-//                  (tile i+1 starts where tile i's traceback stopped), docs/GACT_SPEC.md.
+//   gact3          TWO READS PER WAVEFRONT (packed 16-bit scores, traceback planes in registers): small batches
+//   gact_wide      ONE READ PER WAVEFRONT (32-bit scores, traceback in LDS): bands wider than 128 diagonals, and the
+//                  general fallback (reads with bytes other than ACGT, T - O > 256)
+//                  Tiles of a read are walked in sequence (tile i+1 starts where tile i's traceback stopped),
+//                  docs/GACT_SPEC.md.  Large batches run on the bit-sliced lane-per-read kernel (gact_bs_kernels.hip).
 //
 // GACT tile on a 64-lane wavefront: the band (<=128 diagonals) is laid across the lanes and
 // the wavefront sweeps anti-diagonals s = a+b from the far corner down to the anchor.  On an
@@ -20,7 +23,6 @@
 #include "lrm_internal.h"
 
 #define GACT_NEG (-(1 << 28))
-#define GACT_PAD 96          // guard bytes on both sides of the staged sequences
 #define DPP_WAVE_SHL1 0x130  // lane L <- lane L+1
 #define DPP_WAVE_SHR1 0x138  // lane L <- lane L-1
 
@@ -114,23 +116,6 @@ __global__ __launch_bounds__(256) void revcomp_kernel(char *__restrict__ reads, 
 // ----------------------------------------------------------------------------------------
 // GACT
 // ----------------------------------------------------------------------------------------
-struct GactLds {
-    uint32_t tb_words;     // dwords of traceback per lane (only anti-diagonals a walk can reach)
-    uint32_t seq_bytes;    // bytes of one staged sequence incl. both pads
-    uint32_t ops_bytes;
-    uint32_t wave_bytes;   // total per wavefront
-};
-
-__host__ __device__ inline GactLds gact_lds_layout(int T, int O) {
-    GactLds g;
-    const uint32_t cap2 = 2u * (uint32_t) (T - O);            // a walk never reads a pointer at s >= 2(T-O)
-    g.tb_words = ((cap2 - 1) >> 4) + 1;
-    g.seq_bytes = ((uint32_t) T + 2 * GACT_PAD + 15u) & ~15u;
-    g.ops_bytes = (cap2 + 15u) & ~15u;
-    g.wave_bytes = g.tb_words * 64 * 4 + 2 * g.seq_bytes + g.ops_bytes;
-    return g;
-}
-
 __device__ __forceinline__ int dpp_from_lower(int v, int fill) {   // lane L <- lane L-1, lane 0 <- fill
     return __builtin_amdgcn_update_dpp(fill, v, DPP_WAVE_SHR1, 0xf, 0xf, false);
 }
@@ -156,173 +141,6 @@ __device__ __forceinline__ int gact_cell(int r_diag, int r_ins, int r_del, uint3
     best = is_exit ? 0 : best;
     if (!FULLBAND) best = inband ? best : GACT_NEG;
     return best;
-}
-
-template <bool FULLBAND>
-__global__ __launch_bounds__(256) void gact_kernel(const char *__restrict__ reads, uint64_t stride,
-                                                   const uint32_t *__restrict__ lens,
-                                                   const lrm_seq_meta *__restrict__ meta,
-                                                   const int32_t *__restrict__ meta_r,
-                                                   const char *__restrict__ content,
-                                                   const uint32_t *__restrict__ tlens, uint64_t n_reads,
-                                                   int T, int O, int W, uint8_t *__restrict__ store,
-                                                   uint64_t store_stride, int32_t *__restrict__ n_ops_out,
-                                                   int32_t *__restrict__ score_out, LrmDevCounters *counters,
-                                                   const uint32_t *__restrict__ only) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // everything derived from the wave id is wave-uniform: keep it in SGPRs so that loop control
-    // and the traceback walk run on the scalar unit
-    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    const uint64_t read = (uint64_t) blockIdx.x * 4 + (uint64_t) wave;
-    if (read >= n_reads) return;
-    if (only && !only[read]) return;           // second launch behind the bit-sliced kernel: flagged reads only
-    if (!meta_r[read]) {                       // fenced: no extension (reference would read garbage)
-        if (lane == 0) { n_ops_out[read] = 0; score_out[read] = -1; }
-        return;
-    }
-    const GactLds L = gact_lds_layout(T, O);
-    uint8_t *base = smem + (size_t) wave * L.wave_bytes;
-    uint32_t *tb = reinterpret_cast<uint32_t *>(base);
-    uint8_t *qbuf = base + (size_t) L.tb_words * 256 + GACT_PAD;
-    uint8_t *dbuf = qbuf + L.seq_bytes;
-    uint8_t *opsbuf = base + (size_t) L.tb_words * 256 + 2 * L.seq_bytes;
-
-    const int n = __builtin_amdgcn_readfirstlane((int) lens[read]);
-    const int m = tlens ? __builtin_amdgcn_readfirstlane((int) tlens[read]) : n;   // alnmain.c:443-445: tlen == qlen
-    const uint8_t *q = reinterpret_cast<const uint8_t *>(reads) + read * stride;
-    const uint8_t *d = reinterpret_cast<const uint8_t *>(content) + meta[read].loc;
-    uint8_t *ops_out = store + read * store_stride;
-
-    const int hw = W / 2;
-    const int dE = 2 * lane - 64, dO = 2 * lane - 63;
-    const bool inE = dE >= -hw && dE < hw, inO = dO >= -hw && dO < hw;
-    const int cap = T - O;
-    const int s_hi = (int) L.tb_words * 16 - 1;                  // highest anti-diagonal whose pointers are kept
-
-    int i = 0, j = 0, nops = 0, score = 0;
-    unsigned tiles = 0;
-
-    while (i < n && j < m) {
-        const int tq = (n - i) < T ? (n - i) : T;
-        const int tt = (m - j) < T ? (m - j) : T;
-        const bool last = (i + tq == n);
-        tiles++;
-        // stage the tile's sequences in LDS (coalesced byte loads)
-        for (int x = lane; x < tq; x += 64) qbuf[x] = q[i + x];
-        for (int x = lane; x < tt; x += 64) dbuf[x] = d[j + x];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        const int eE = min(2 * tq + dE, 2 * tt - dE);            // first step at/after which lane is exit/outside
-        const int eO = min(2 * tq + dO, 2 * tt - dO);
-        int r1 = GACT_NEG, r2 = GACT_NEG;                        // R at s+1 and s+2 for this lane
-        uint32_t acc = 0;
-        int s = tq + tt;
-        // Per-lane sequence cursors.  Odd steps move one query base down (a--), even steps one
-        // target base down (b--); the base needed by the NEXT step of each kind is prefetched so
-        // the LDS latency sits under a whole step pair.
-        const uint8_t *qp, *dp;
-        uint32_t qc = 0, dc = 0, qn, dn;
-        if ((s & 1) == 0) {          // first step is even: a = s/2+32-lane is current, b steps down into s/2-32+lane
-            qp = qbuf + (s / 2 + 32 - lane);
-            dp = dbuf + (s / 2 - 32 + lane) + 1;
-            qc = *qp;
-        } else {                     // first step is odd: b = (s-1)/2-31+lane is current, a steps down into (s-1)/2+32-lane
-            qp = qbuf + ((s - 1) / 2 + 32 - lane) + 1;
-            dp = dbuf + ((s - 1) / 2 - 31 + lane);
-            dc = *dp;
-        }
-        qn = qp[-1];
-        dn = dp[-1];
-
-#define GACT_ODD(TRACK, S) do {                                                        \
-            qc = qn; qp -= 1; qn = qp[-1];                                                 \
-            int del_ = dpp_from_upper(r1, GACT_NEG);                                       \
-            int r0_ = gact_cell<TRACK, FULLBAND>(r2, r1, del_, qc, dc, (S) >= eO, inO, acc); \
-            r2 = r1; r1 = r0_;                                                             \
-        } while (0)
-#define GACT_EVEN(TRACK, S) do {                                                       \
-            dc = dn; dp -= 1; dn = dp[-1];                                                 \
-            int ins_ = dpp_from_lower(r1, GACT_NEG);                                       \
-            int r0_ = gact_cell<TRACK, FULLBAND>(r2, ins_, r1, qc, dc, (S) >= eE, inE, acc); \
-            r2 = r1; r1 = r0_;                                                             \
-        } while (0)
-
-        // phase A: anti-diagonals no walk can reach -- scores only
-        if (s > s_hi && (s & 1) == 0) { GACT_EVEN(false, s); s--; }
-        for (; s - 1 > s_hi; s -= 2) { GACT_ODD(false, s); GACT_EVEN(false, s - 1); }
-        if (s > s_hi) { GACT_ODD(false, s); s--; }
-        // phase B: scores + traceback pointers, 16 steps per dword
-        if (s >= 0 && (s & 1) == 0) {
-            GACT_EVEN(true, s);
-            if ((s & 15) == 0) tb[(s >> 4) * 64 + lane] = acc;
-            s--;
-        }
-        for (; s >= 1; s -= 2) {
-            GACT_ODD(true, s);
-            GACT_EVEN(true, s - 1);
-            if (((s - 1) & 15) == 0) tb[((s - 1) >> 4) * 64 + lane] = acc;
-        }
-#undef GACT_ODD
-#undef GACT_EVEN
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        // Traceback walk from the anchor.  All state is wave-uniform.  One traceback dword holds 16
-        // anti-diagonals of one band lane, and a DIAG move keeps the lane (s += 2), so a whole run
-        // of DIAG moves is decoded from one LDS read with bit tricks: the run length is a
-        // count-trailing-zeros over the "is a gap" bits, its mismatches a popcount, and its op bytes
-        // are written by as many lanes at once.  The gap that ends the run is taken in the same
-        // iteration.  ~1 iteration per indel or per 8 DIAG moves instead of 1 per alignment column.
-        int a = 0, b = 0, cnt = 0;
-        const int lim2 = 2 * cap;
-        while (a < tq && b < tt && (last ? (a + b < lim2) : (a < cap && b < cap))) {
-            const int sw = a + b, dd = b - a, e0 = sw & 15;
-            const uint32_t word = __builtin_amdgcn_readfirstlane(tb[(sw >> 4) * 64 + ((dd + 64) >> 1)]);
-            const uint32_t par = (e0 & 1) ? 0x44444444u : 0x11111111u;      // entries of this walk's parity
-            const uint32_t from = 0xFFFFFFFFu << (2 * e0);
-            const uint32_t gm = (word ^ (word >> 1)) & par & from;            // entries holding INS (01) / DEL (10)
-            const int egap = gm ? (__builtin_ctz(gm) >> 1) : 16 + (e0 & 1);
-            const int r = (egap - e0) >> 1;                                   // DIAG moves before the gap / word end
-            int rmax = min(tq - a, tt - b);
-            rmax = last ? min(rmax, (lim2 - sw + 1) >> 1) : min(rmax, min(cap - a, cap - b));
-            const int rr = min(r, rmax);
-            const int eend = e0 + 2 * rr;
-            const uint32_t below = eend >= 16 ? 0xFFFFFFFFu : ((1u << (2 * eend)) - 1u);
-            const uint32_t mm = word & (word >> 1) & par & from & below;      // DIAG/mismatch entries (11) in the run
-            if (lane < rr) opsbuf[cnt + lane] = ((word >> (2 * (e0 + 2 * lane))) & 3u) ? 'X' : '=';
-            const int a2 = a + rr, b2 = b + rr;
-            const bool more = a2 < tq && b2 < tt && (last ? (a2 + b2 < lim2) : (a2 < cap && b2 < cap));
-            const bool do_gap = gm != 0u && rr == r && more;
-            const uint32_t gp = (word >> (2 * (egap & 15))) & 3u;             // 1 INS, 2 DEL when do_gap
-            if (do_gap && lane == 0) opsbuf[cnt + rr] = gp == 1u ? 'I' : 'D';
-            score += __builtin_popcount(mm) + (do_gap ? 1 : 0);
-            cnt += rr + (do_gap ? 1 : 0);
-            a = a2 + ((do_gap && gp == 1u) ? 1 : 0);
-            b = b2 + ((do_gap && gp == 2u) ? 1 : 0);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (int x = lane; x < cnt; x += 64) ops_out[nops + x] = opsbuf[x];
-        nops += cnt;
-        i += a;
-        j += b;
-        if (a + b == 0) { score = -1; break; }                   // cannot happen (T-O >= 1); never spin
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (score >= 0 && i < n) {                                   // target exhausted: rest of the query is inserted
-        int rest = n - i;
-        for (int x = lane; x < rest; x += 64) ops_out[nops + x] = 'I';
-        nops += rest;
-        score += rest;
-    }
-    if (lane == 0) {
-        n_ops_out[read] = score >= 0 ? nops : 0;
-        score_out[read] = score;
-        atomicAdd(&counters->gact_tiles, (unsigned long long) tiles);
-    }
 }
 
 // ----------------------------------------------------------------------------------------
@@ -660,8 +478,10 @@ __global__ __launch_bounds__(256) void gact3_kernel(const char *__restrict__ rea
 }
 
 // ----------------------------------------------------------------------------------------
-// GACT, wide bands (128 < W <= 1024, e.g. the full-tile band W = T of the config-4 sweep).
-// Same sweep as gact_kernel, but every lane owns DPL diagonal pairs: diagonal index x = lane + 64*g
+// GACT, one read per wavefront, 32-bit scores: wide bands (128 < W <= 1024, e.g. the full-tile band W = T of the
+// config-5 sweep; DPL = 2, 4, 8) and, with DPL = 1, the general fallback for what the fast kernels do not take:
+// reads holding a byte other than ACGT behind the bit-sliced kernel, and tiles with T - O > 256 in small batches.
+// The wavefront sweeps anti-diagonals from the tile's far corner to the anchor; every lane owns DPL diagonal pairs: diagonal index x = lane + 64*g
 // (g < DPL), d = 2x - 64*DPL (+1 on odd anti-diagonals).  The neighbour of a group's edge lane is the
 // opposite edge lane of the adjacent group (one v_readlane per group and step).  One wavefront per
 // workgroup: the traceback of a wide band needs up to 128 KiB of LDS.  Simple form (32-bit scores,
@@ -676,7 +496,8 @@ __global__ __launch_bounds__(64) void gact_wide_kernel(const char *__restrict__ 
                                                        const uint32_t *__restrict__ tlens, uint64_t n_reads,
                                                        int T, int O, int W, uint8_t *__restrict__ store,
                                                        uint64_t store_stride, int32_t *__restrict__ n_ops_out,
-                                                       int32_t *__restrict__ score_out, LrmDevCounters *counters) {
+                                                       int32_t *__restrict__ score_out, LrmDevCounters *counters,
+                                                       const uint32_t *__restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int NX = 64 * DPL;                   // diagonal indices per parity
     constexpr int HWX = NX;                        // d = 2x - HWX (+1)
@@ -684,6 +505,7 @@ __global__ __launch_bounds__(64) void gact_wide_kernel(const char *__restrict__ 
     const int lane = threadIdx.x & 63;
     const uint64_t read = blockIdx.x;
     if (read >= n_reads) return;
+    if (flags && !flags[read]) return;             // second launch behind the bit-sliced kernel: flagged reads only
     if (!meta_r[read]) {
         if (lane == 0) { n_ops_out[read] = 0; score_out[read] = -1; }
         return;
@@ -798,9 +620,6 @@ __global__ __launch_bounds__(64) void gact_wide_kernel(const char *__restrict__ 
     }
 }
 
-typedef void (*gact_fn_t)(const char *, uint64_t, const uint32_t *, const lrm_seq_meta *, const int32_t *,
-                          const char *, const uint32_t *, uint64_t, int, int, int, uint8_t *, uint64_t, int32_t *,
-                          int32_t *, LrmDevCounters *);
 typedef void (*gact1_fn_t)(const char *, uint64_t, const uint32_t *, const lrm_seq_meta *, const int32_t *,
                            const char *, const uint32_t *, uint64_t, int, int, int, uint8_t *, uint64_t, int32_t *,
                            int32_t *, LrmDevCounters *, const uint32_t *);
@@ -808,28 +627,36 @@ typedef void (*gact2_fn_t)(const char *, uint64_t, const uint32_t *, const lrm_s
                            const char *, const uint32_t *, uint64_t, int, int, int, uint8_t *, uint64_t, int32_t *,
                            int32_t *, LrmDevCounters *);
 
+// one read per wavefront (gact_wide_kernel): DPL diagonal pairs per lane for the band W; flags != null: flagged reads only
+static int launch_one_per_wave(lrm_gact_params gp, uint64_t n, hipStream_t stream, const char *reads, uint64_t stride,
+                               const uint32_t *lens, const lrm_seq_meta *meta, const int32_t *meta_r, const char *content,
+                               const uint32_t *tlens, uint8_t *store, uint64_t store_stride, int32_t *n_ops, int32_t *score,
+                               LrmDevCounters *counters, const uint32_t *flags) {
+    const int dpl = gp.W <= 128 ? 1 : gp.W <= 256 ? 2 : gp.W <= 512 ? 4 : 8;
+    const int nx = 64 * dpl, padw = nx / 2 + 40;
+    const int tbw = ((2 * (gp.T - gp.O) - 1) >> 4) + 1;
+    const int seqb = (gp.T + 2 * padw + 15) & ~15;
+    size_t shw = (size_t) tbw * nx * 4 + 2 * (size_t) seqb + (((size_t) 2 * (gp.T - gp.O) + 15) & ~(size_t) 15);
+    if (shw > 160 * 1024) { lrm_set_error("GACT T=%d O=%d W=%d needs %zu B of LDS (> 160 KiB)", gp.T, gp.O, gp.W, shw); return -1; }
+    gact1_fn_t fw = dpl == 1 ? gact_wide_kernel<1> : dpl == 2 ? gact_wide_kernel<2> : dpl == 4 ? gact_wide_kernel<4> : gact_wide_kernel<8>;
+    if (shw > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fw),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) shw);
+        if (e != hipSuccess) { lrm_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", shw, hipGetErrorString(e)); return -1; }
+    }
+    if (n > 0x7fffffffull) { lrm_set_error("gact grid too large: split the batch"); return -1; }
+    hipLaunchKernelGGL(fw, dim3((uint32_t) n), dim3(64), shw, stream, reads, stride, lens, meta, meta_r, content,
+                       tlens, n, gp.T, gp.O, gp.W, store, store_stride, n_ops, score, counters, flags);
+    return 0;
+}
+
 static int gact_launch(lrm_gact_params gp, uint64_t n, hipStream_t stream, const char *reads, uint64_t stride,
                        const uint32_t *lens, const lrm_seq_meta *meta, const int32_t *meta_r, const char *content,
                        const uint32_t *tlens, uint8_t *store, uint64_t store_stride, int32_t *n_ops, int32_t *score,
                        LrmDevCounters *counters, const LrmBsArgs *bs) {
-    if (gp.W > 128) {
-        int dpl = gp.W <= 256 ? 2 : gp.W <= 512 ? 4 : 8;
-        const int nx = 64 * dpl, padw = nx / 2 + 40;
-        const int tbw = ((2 * (gp.T - gp.O) - 1) >> 4) + 1;
-        const int seqb = (gp.T + 2 * padw + 15) & ~15;
-        size_t shw = (size_t) tbw * nx * 4 + 2 * (size_t) seqb + (((size_t) 2 * (gp.T - gp.O) + 15) & ~(size_t) 15);
-        if (shw > 160 * 1024) { lrm_set_error("GACT T=%d O=%d W=%d needs %zu B of LDS (> 160 KiB)", gp.T, gp.O, gp.W, shw); return -1; }
-        gact_fn_t fw = dpl == 2 ? gact_wide_kernel<2> : dpl == 4 ? gact_wide_kernel<4> : gact_wide_kernel<8>;
-        if (shw > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fw),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) shw);
-            if (e != hipSuccess) { lrm_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", shw, hipGetErrorString(e)); return -1; }
-        }
-        if (n > 0x7fffffffull) { lrm_set_error("gact grid too large: split the batch"); return -1; }
-        hipLaunchKernelGGL(fw, dim3((uint32_t) n), dim3(64), shw, stream, reads, stride, lens, meta, meta_r, content,
-                           tlens, n, gp.T, gp.O, gp.W, store, store_stride, n_ops, score, counters);
-        return 0;
-    }
+    if (gp.W > 128)
+        return launch_one_per_wave(gp, n, stream, reads, stride, lens, meta, meta_r, content, tlens, store, store_stride,
+                                   n_ops, score, counters, nullptr);
     // LRM_GACT_IMPL (read at every call so that tests can switch): 0 = automatic, 1 = one read per wavefront,
     // 3 = packed two reads per wavefront, 4 = bit-sliced lane per read whenever it applies (W <= 128, pure ACGT
     // text, 4-byte aligned CIGAR store; otherwise as 0)
@@ -842,18 +669,9 @@ static int gact_launch(lrm_gact_params gp, uint64_t n, hipStream_t stream, const
     if (bs_ok && (impl == 4 || (impl == 0 && n >= LRM_BS_MIN_READS))) {
         if (lrm_bs_launch(bs, lens, meta, meta_r, tlens, n, gp.T, gp.O, gp.W, store, store_stride, n_ops, score, counters,
                           stream)) return -1;
-        // reads holding a byte other than ACGT (rare): byte kernel, flagged reads only
-        GactLds L1 = gact_lds_layout(gp.T, gp.O);
-        size_t sh1 = (size_t) L1.wave_bytes * 4;
-        gact1_fn_t f1 = gp.W >= 128 ? gact_kernel<true> : gact_kernel<false>;
-        if (sh1 > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(f1),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) sh1);
-            if (e != hipSuccess) { lrm_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", sh1, hipGetErrorString(e)); return -1; }
-        }
-        hipLaunchKernelGGL(f1, dim3((uint32_t) ((n + 3) / 4)), dim3(256), sh1, stream, reads, stride, lens, meta, meta_r,
-                           content, tlens, n, gp.T, gp.O, gp.W, store, store_stride, n_ops, score, counters, bs->flags);
-        return 0;
+        // reads holding a byte other than ACGT (rare): one read per wavefront, flagged reads only
+        return launch_one_per_wave(gp, n, stream, reads, stride, lens, meta, meta_r, content, tlens, store, store_stride,
+                                   n_ops, score, counters, bs->flags);
     }
     if (impl != 1 && nblk <= 32) {
         size_t shmem3 = (size_t) 4 * 2 * ((size_t) gp.T + 2 * G2_PAD) * 4;
@@ -865,19 +683,9 @@ static int gact_launch(lrm_gact_params gp, uint64_t n, hipStream_t stream, const
                            content, tlens, n, gp.T, gp.O, gp.W, store, store_stride, n_ops, score, counters);
         return 0;
     }
-    GactLds L = gact_lds_layout(gp.T, gp.O);
-    size_t shmem = (size_t) L.wave_bytes * 4;
-    gact1_fn_t fn = gp.W >= 128 ? gact_kernel<true> : gact_kernel<false>;
-    if (shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
-        if (e != hipSuccess) { lrm_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", shmem, hipGetErrorString(e)); return -1; }
-    }
-    uint64_t blocks = (n + 3) / 4;
-    hipLaunchKernelGGL(fn, dim3((uint32_t) blocks), dim3(256), shmem, stream, reads, stride, lens, meta, meta_r,
-                       content, tlens, n, gp.T, gp.O, gp.W, store, store_stride, n_ops, score, counters,
-                       (const uint32_t *) nullptr);
-    return 0;
+    // T - O > 256 (more traceback planes than the packed kernel keeps in registers) or LRM_GACT_IMPL=1
+    return launch_one_per_wave(gp, n, stream, reads, stride, lens, meta, meta_r, content, tlens, store, store_stride,
+                               n_ops, score, counters, nullptr);
 }
 
 // ----------------------------------------------------------------------------------------

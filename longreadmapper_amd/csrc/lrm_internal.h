@@ -115,7 +115,10 @@ struct LrmDevCounters {
 #define LRM_ERR_VOTE_OVERFLOW 1u
 // vote tiers (seed_kernels.hip): hits per (read, phase) item up to which one wavefront / one workgroup pass suffices
 #define LRM_VOTE_T1_LIMIT 192
-#define LRM_VOTE_T3_LIMIT 1152
+#ifndef LRM_VOTE_T3_SLOTS
+#define LRM_VOTE_T3_SLOTS 1024
+#endif
+#define LRM_VOTE_T3_LIMIT (LRM_VOTE_T3_SLOTS * 3 / 4)
 
 enum LrmKernelId { LRM_K_PACK2BIT = 0, LRM_K_SEED_SEARCH, LRM_K_VOTE, LRM_K_DECIDE,
                    LRM_K_LOCUS, LRM_K_REVCOMP, LRM_K_GACT, LRM_K_PACK_PLANAR, LRM_K_GACT_BS,

@@ -359,9 +359,9 @@ __global__ __launch_bounds__(256) void seed_search_debug_kernel(LrmIndexView ix,
 #define VG_MAX 64
 #define T1_SLOTS 256
 #define T1_LIMIT LRM_VOTE_T1_LIMIT
-#define T3_SLOTS 1536
+#define T3_SLOTS LRM_VOTE_T3_SLOTS
 #define T3_LIMIT LRM_VOTE_T3_LIMIT
-#define T3_CHUNK 512            // survivors per prefix chunk of the workgroup tier (2 per thread)
+#define T3_CHUNK 256                  // survivors per prefix chunk of the workgroup tier: one per thread
 #define EMPTY32 0xFFFFFFFFu
 
 // never a vote key: keys are SA - j (u64 wrap) with SA < 2^40 and j < 2^32, i.e. in [0, 2^40) or [2^64 - 2^32, 2^64)
@@ -628,18 +628,16 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
         bool ok = true;
         for (uint32_t c0 = 0; c0 < cnt; c0 += T3_CHUNK) {
             const uint32_t nc = cnt - c0 < (uint32_t) T3_CHUNK ? cnt - c0 : (uint32_t) T3_CHUNK;
-            // two consecutive survivors per thread; unique seeds gather at once, repeat seeds are compacted into LDS
-            const uint32_t s0 = 2 * tid, s1 = s0 + 1;
-            const uint64_t e0 = s0 < nc ? rec[c0 + s0] : 0ull, e1 = s1 < nc ? rec[c0 + s1] : 0ull;
-            const uint32_t q0 = s0 < nc ? recq[c0 + s0] : 0u, q1 = s1 < nc ? recq[c0 + s1] : 0u;
-            const uint32_t r0 = (uint32_t) (e0 >> 40), r1 = (uint32_t) (e1 >> 40);
+            // one survivor per thread; unique seeds gather at once, repeat seeds are compacted into LDS
+            const uint64_t e0 = tid < nc ? rec[c0 + tid] : 0ull;
+            const uint32_t q0 = tid < nc ? recq[c0 + tid] : 0u;
+            const uint32_t r0 = (uint32_t) (e0 >> 40);
             const uint64_t v0 = r0 == 1 ? sa_locate(ix, e0 & ((1ull << 40) - 1ull)) : 0ull;
-            const uint64_t v1 = r1 == 1 ? sa_locate(ix, e1 & ((1ull << 40) - 1ull)) : 0ull;
-            const uint32_t b0 = r0 > 1 ? 1u : 0u, b1 = r1 > 1 ? 1u : 0u;
-            const uint32_t h0 = b0 ? r0 : 0u, h1 = b1 ? r1 : 0u;
-            const uint32_t incl_h = wave_incl_scan(h0 + h1), incl_n = wave_incl_scan(b0 + b1);
+            const uint32_t b0 = r0 > 1 ? 1u : 0u, h0 = b0 ? r0 : 0u;
+            const unsigned long long bm = __ballot(b0 != 0);
+            const uint32_t incl_h = wave_incl_scan(h0);
             __syncthreads();                                   // the previous chunk's (or pass's) staging is no longer read
-            if (lane == 63) { s_wsum[wave] = incl_h; s_wsum[4 + wave] = incl_n; }
+            if (lane == 63) { s_wsum[wave] = incl_h; s_wsum[4 + wave] = (uint32_t) __popcll(bm); }
             __syncthreads();
             uint32_t woff_h = 0, total = 0, woff_n = 0, nbig = 0;
 #pragma unroll
@@ -648,13 +646,13 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
                 total += x; nbig += y;
                 if (w < wave) { woff_h += x; woff_n += y; }
             }
-            const uint32_t excl_h = woff_h + incl_h - (h0 + h1), excl_n = woff_n + incl_n - (b0 + b1);
-            if (b0) { L.off[excl_n] = excl_h; L.srec[excl_n] = e0; L.sq[excl_n] = q0; }
-            if (b1) { L.off[excl_n + b0] = excl_h + h0; L.srec[excl_n + b0] = e1; L.sq[excl_n + b0] = q1; }
+            if (b0) {
+                const uint32_t idx = woff_n + mask_rank(bm);
+                L.off[idx] = woff_h + incl_h - h0; L.srec[idx] = e0; L.sq[idx] = q0;
+            }
             if (tid == 0) L.off[nbig] = total;
             __syncthreads();
             if (r0 == 1) ok &= vote_admit(t, v0 - (uint64_t) (iter + q0 * P), q0 << tbits, passes, pass);
-            if (r1 == 1) ok &= vote_admit(t, v1 - (uint64_t) (iter + q1 * P), q1 << tbits, passes, pass);
             if (nbig) ok &= vote_hits<256, VOTE_U>(ix, t, L.off, L.srec, L.sq, nbig, total, iter, P, tbits, tid, passes, pass);
         }
         if (!ok) *(volatile uint32_t *) err_word = LRM_ERR_VOTE_OVERFLOW;   // host-coherent, sticky
@@ -698,8 +696,12 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
     if (tid == 0) write_phase(out, best);
 }
 
+#ifndef LRM_VOTE_WAVES_PER_EU
+#define LRM_VOTE_WAVES_PER_EU 6     // 79 VGPRs and 23.7 KB of LDS per workgroup: six workgroups per CU
+#endif
 template <int VOTE_U>
-__global__ __launch_bounds__(256) void vote_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LRM_VOTE_WAVES_PER_EU, LRM_VOTE_WAVES_PER_EU)))
+void vote_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
                                                    const uint32_t *__restrict__ recq,
                                                    const uint32_t *__restrict__ gcnt,
                                                    const uint32_t *__restrict__ ghits,
@@ -865,7 +867,7 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
     }
     // tuning knobs (measured defaults; tools/seed_probe.py sweeps them)
     uint32_t vg = VG, t1_limit = T1_LIMIT;
-    int vote_u = 4;
+    int vote_u = 2;
     if (const char *e = getenv("LRM_VOTE_VG")) { const int v = atoi(e); if (v >= 1 && v <= VG_MAX) vg = (uint32_t) v; }
     if (const char *e = getenv("LRM_VOTE_T1")) { const int v = atoi(e); if (v >= 0 && v <= T1_LIMIT) t1_limit = (uint32_t) v; }
     if (const char *e = getenv("LRM_VOTE_U")) vote_u = atoi(e);

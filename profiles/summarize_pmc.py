@@ -64,7 +64,10 @@ for k, v in per_kernel.items():
     e = dict(launches_per_step=int(v["launches_per_step"]), ms=v.get("ms"), fetch_bytes=v.get("FETCH_SIZE", 0) * 1024,
              write_bytes=v.get("WRITE_SIZE", 0) * 1024, l2_hit=hit, l2_miss=miss, valu_insts=v.get("SQ_INSTS_VALU"),
              salu_insts=v.get("SQ_INSTS_SALU"), vmem_rd=v.get("SQ_INSTS_VMEM_RD"), wave_cycles_q=v.get("SQ_WAVE_CYCLES"),
-             wait_any_q=v.get("SQ_WAIT_ANY"), active_valu_q=v.get("SQ_ACTIVE_INST_VALU"), waves=v.get("SQ_WAVES"))
+             wait_any_q=v.get("SQ_WAIT_ANY"), active_valu_q=v.get("SQ_ACTIVE_INST_VALU"), waves=v.get("SQ_WAVES"),
+             lds_insts=v.get("SQ_INSTS_LDS"), lds_active_q=v.get("SQ_ACTIVE_INST_LDS"), lds_bank_conflict=v.get("SQ_LDS_BANK_CONFLICT"),
+             lds_idx_active=v.get("SQ_LDS_IDX_ACTIVE"), lds_addr_conflict=v.get("SQ_LDS_ADDR_CONFLICT"),
+             wait_inst_any_q=v.get("SQ_WAIT_INST_ANY"), active_inst_any_q=v.get("SQ_ACTIVE_INST_ANY"), busy_cycles=v.get("SQ_BUSY_CYCLES"))
     summary["kernels"][k] = e
     lines.append("| %s | %d | %.2f | %.2f | %.2f | %s | %s | %s |" % (
         k, e["launches_per_step"], e["ms"] or 0, e["fetch_bytes"] / 1e9, e["write_bytes"] / 1e9,

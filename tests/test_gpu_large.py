@@ -1,0 +1,42 @@
+"""Rows and suffix-array values beyond 2^32 through the whole GPU path, against the oracle: a 2.2 Gbp synthetic
+reference (4.4 G rows: more than 2^32, so `k`, `l`, SA values and loci all need their high bits), built by the
+product's parallel suffix sorter.  Needs ~75 GB of host RAM and ~2 minutes, so it only runs with LRM_TEST_LARGE=1
+(`profiles/r2/large_test.log` holds the round-2 run); bench.py --ref-len 3099750718 asserts the same equality on
+the GRCh38-sized text inside every run."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from longreadmapper_amd import index, mapper, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.skipif(os.environ.get("LRM_TEST_LARGE") != "1", reason="set LRM_TEST_LARGE=1 (75 GB of host RAM, ~2 min)")
+def test_rows_beyond_2p32_end_to_end(gpu):
+    n_ref = 2_200_000_000
+    ref = synth.reference(n_ref, seed=5, repeat_frac=0.02, rep_len=300, rep_copies=500, rep_div=0.05)
+    hi = index.HostIndex.build([ref], hlen=12)
+    assert hi.length == 2 * n_ref + 1 > 1 << 32
+    r = synth.reads([ref], 3000, 5000, synth.ONT, seed=9)
+    oi = orc.OracleIndex.from_host_index(hi)
+    want, _ = oi.seed_batch(r["reads"], r["lens"], nthreads=16)
+    rc = r["reads"].copy()
+    wext = oi.extend_batch(rc, r["lens"], want, nthreads=16)
+    assert (want["key"] >= np.uint64(1 << 32)).mean() > 0.3                # loci in the upper part of the text
+    di = index.DeviceIndex.upload(hi, gpu)
+    try:
+        rg = r["reads"].copy()
+        got = mapper.map_batch(di, rg, r["lens"])
+        assert np.array_equal(got["best"], want)
+        assert np.array_equal(got["score"], wext["score"]) and np.array_equal(got["n_ops"], wext["n_ops"])
+        assert np.array_equal(got["meta"]["loc"], wext["meta"]["loc"]) and np.array_equal(rg, rc)
+        for i in range(0, 3000, 37):
+            k = int(wext["n_ops"][i])
+            assert bytes(got["ops"][i, :k]) == bytes(wext["ops"][i, :k]), i
+        near = (np.abs(got["meta"]["off"].astype(np.int64) - r["pos"].astype(np.int64)) < 300) & (got["meta"]["strand"] == r["strand"])
+        assert near.mean() > 0.97
+    finally:
+        di.close()

@@ -10,5 +10,9 @@ from longreadmapper_amd import _build
 out = os.path.join(_build.ROOT, "tools", "_probe_libs")
 os.makedirs(out, exist_ok=True)
 for v in sys.argv[1:]:
-    p = os.path.join(out, "liblrm_accel_vp%s.so" % v)
-    print(_build.build_accel(force=True, defines=["LRM_VOTE_PROBE=" + v], out=p))
+    if "=" in v:                       # any -D define, e.g. LRM_VOTE_T3_SLOTS=1024
+        p = os.path.join(out, "liblrm_accel_%s.so" % v.replace("=", "_"))
+        print(_build.build_accel(force=True, defines=[v], out=p))
+    else:
+        p = os.path.join(out, "liblrm_accel_vp%s.so" % v)
+        print(_build.build_accel(force=True, defines=["LRM_VOTE_PROBE=" + v], out=p))
