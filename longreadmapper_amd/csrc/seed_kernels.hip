@@ -202,11 +202,13 @@ __global__ __launch_bounds__(256) void lcl_build_kernel(LrmIndexView ix, int hl,
     out[code] = e;
 }
 
-// LRM_LC_LONG: 0 = off, 13..16 = that k-mer length, unset = automatic: 16 (32 GiB) once the occ table is far
-// beyond the caches -- every backward step is then an HBM-random request: -32 % seed_search time on a chr1-sized
-// text.  On an E. coli-sized text the saved steps were cache hits and the bigger table costs 3-4 %: off.
+// LRM_LC_LONG: 0 = off, 13..16 = that k-mer length, unset = automatic:
+//   16 (32 GiB) once the occ table is far beyond the caches -- every backward step is then an HBM-random request:
+//      -32 % seed_search time on a chr1-sized text [r1];
+//   13 (512 MiB) on small texts: one step less per seed from a table that still mostly sits in the Infinity Cache:
+//      -2.7 % on the E. coli-sized text [r2] (14, 2 GiB, loses 2 %: its lookups go to HBM).
 int lrm_lcl_prepare_index(lrm_index *idx) {
-    int hl = idx->view.length >= (1ull << 26) ? 16 : 0;
+    int hl = idx->view.length >= (1ull << 26) ? 16 : 13;
     if (const char *e = getenv("LRM_LC_LONG")) hl = atoi(e);
     if (hl <= idx->view.hlen || hl > 16 || idx->view.length < 2) return 0;
     uint64_t *d = nullptr;

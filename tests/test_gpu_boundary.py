@@ -47,8 +47,9 @@ def test_map_batch_equals_the_two_calls_and_the_oracle(ont, monkeypatch, env):
     assert np.array_equal(r, r_cpu)                      # reverse-strand reads rev-comped in the caller's buffer
 
 
-def test_map_batch_with_pinned_caller_buffers(ont):
-    """Buffers from lrm_host_alloc are handed to the DMA engines directly (no staging copy): same results."""
+def test_map_batch_with_pinned_caller_buffers(ont, monkeypatch):
+    """Buffers from lrm_host_alloc are handed to the DMA engines directly (no staging copy): same results; also with
+    LRM_HOST_DIRECT=1, where the device writes the result rows straight into the pinned caller buffers."""
     sc, di, oi, best, ext, r_cpu = ont
     n, stride = sc["reads"].shape
     r = mapper.pinned_empty((n, stride))
@@ -60,6 +61,13 @@ def test_map_batch_with_pinned_caller_buffers(ont):
         assert np.array_equal(got["best"], best)
         _assert_ext_equal(got, ext, n, "pinned")
         assert np.array_equal(r, r_cpu)
+        monkeypatch.setenv("LRM_HOST_DIRECT", "1")
+        r[:] = sc["reads"]
+        store[:] = 0
+        got = mapper.map_batch(di, r, sc["lens"], sc["seed_len"], sc["thres"], store=store)
+        monkeypatch.delenv("LRM_HOST_DIRECT")
+        assert np.array_equal(got["best"], best) and np.array_equal(r, r_cpu)
+        _assert_ext_equal(got, ext, n, "pinned, direct device writes")
         # registered caller memory (what a maintainer does with the malloc'd buffers of alnmain.c:297-320)
         r2 = np.ascontiguousarray(sc["reads"].copy())
         capi.check(capi.lib.lrm_host_register(r2.ctypes.data, r2.nbytes), "lrm_host_register")
