@@ -102,7 +102,8 @@ def main():
 
     # OpenMP (index builder, staging copies, the CPU oracle) must not spawn one thread per hardware thread of the
     # host when the job only owns a share of it (cgroup quota): oversubscribed threads are throttled
-    os.environ.setdefault("OMP_NUM_THREADS", str(usable_cpus()))
+    # (and the ranks of one node share that share)
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))))))
 
     import torch
     import torch.distributed as tdist
@@ -274,7 +275,7 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
     oi = orc.OracleIndex.from_host_index(hi)
-    cores = min(orc.lib.orc_max_threads(), usable_cpus())
+    cores = min(orc.lib.orc_max_threads(), usable_cpus())          # rank 0 alone runs the CPU baseline
     cpu = None
     per_base = None
     sample_n = min(n, 4 * cores)

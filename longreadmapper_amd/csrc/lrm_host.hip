@@ -9,7 +9,7 @@
 // How a slice of a batch goes through a device: its arrays are mirrored whole in HBM; the reads are uploaded and
 // SEEDED in sub-batches (three seed streams, round robin: the first kernels start a few milliseconds into the
 // call and the uploads hide behind them), the EXTENSION runs over groups of sub-batches on its own stream as soon
-// as their seeds are done (the bit-sliced kernel carries one read per lane and wants ~25 k reads per launch;
+// as their seeds are done, two groups at a time on two streams (the bit-sliced kernel carries one read per lane;
 // the memory-latency-bound seed kernels of later sub-batches overlap its VALU-bound work), and a second host
 // thread downloads every group while the next one is extended.  Results leave the device DENSE: a pack kernel
 // gathers the used part of every CIGAR row and the reverse-complemented reads (the only rows of reads_buf that
@@ -58,6 +58,7 @@ struct DevSlot {
 };
 constexpr uint64_t STAGE_CHUNK = 32ull << 20;
 constexpr int N_SEED_STREAMS = 3;
+constexpr int N_EXT_STREAMS = 2;        // two groups in extension at once: a 25 k-read group fills a third of the SIMDs
 constexpr int COPY_THREADS = 8;       // enough to outrun the link; a library must not fan out over every core of its host
 struct DevSet { DevSlot reads, lens, best, store, nops, score, meta, mr, dense, offs; };
 
@@ -66,10 +67,10 @@ struct DevSet { DevSlot reads, lens, best, store, nops, score, meta, mr, dense, 
 struct LrmHostCtx {
     std::mutex mu;                       // one host-buffer call at a time per replica (re-entrant per handle otherwise)
     lrm_workspace *ws_seed[N_SEED_STREAMS] = {};   // seed-stage scratch, one per seed stream (sub-batch sized)
-    lrm_workspace *ws_ext = nullptr;               // extension scratch (group sized)
+    lrm_workspace *ws_ext[N_EXT_STREAMS] = {};     // extension scratch (group sized), one per extension stream
     DevSet dev;                                    // device mirrors of the caller's arrays for one slice
     void *pin_up[2] = {nullptr, nullptr}, *pin_dn[2] = {nullptr, nullptr};
-    hipStream_t up = nullptr, down = nullptr, seed[N_SEED_STREAMS] = {}, ext = nullptr;
+    hipStream_t up = nullptr, down = nullptr, seed[N_SEED_STREAMS] = {}, ext[N_EXT_STREAMS] = {};
     hipEvent_t ev_pin_up[2] = {nullptr, nullptr}, ev_pin_dn[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> ev_up, ev_seed, ev_ext;   // per sub-batch / per extension group, grown on demand
     bool pin_up_used[2] = {false, false};
@@ -94,8 +95,9 @@ int ctx_init(LrmHostCtx &c) {
     (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);          // numerically lower = higher priority
     const int p_seed = prio_lo, p_ext = prio_hi < prio_lo ? prio_lo - 1 : prio_lo, p_down = prio_hi;
     if (hipStreamCreateWithPriority(&c.up, hipStreamNonBlocking, p_down) != hipSuccess ||
-        hipStreamCreateWithPriority(&c.down, hipStreamNonBlocking, p_down) != hipSuccess ||
-        hipStreamCreateWithPriority(&c.ext, hipStreamNonBlocking, p_ext) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
+        hipStreamCreateWithPriority(&c.down, hipStreamNonBlocking, p_down) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
+    for (int s = 0; s < N_EXT_STREAMS; ++s)
+        if (hipStreamCreateWithPriority(&c.ext[s], hipStreamNonBlocking, p_ext) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
     for (int s = 0; s < N_SEED_STREAMS; ++s)
         if (hipStreamCreateWithPriority(&c.seed[s], hipStreamNonBlocking, p_seed) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
     c.ready = true;
@@ -251,8 +253,9 @@ uint64_t pipe_subs(uint64_t n) {
     return k < 2 ? 1 : (k > 12 ? 12 : k);
 }
 // Sub-batches per extension group: the bit-sliced kernel carries one read per LANE, so it wants >= 32 k reads
-// per launch to put a wavefront on a good part of the chip's SIMDs (measured: 25 k-read groups beat 37 k and 17 k).
-constexpr uint64_t EXT_GROUP_READS = 24576;
+// per launch for decent SIMD coverage; two groups are in extension at once (two streams).  Measured per 100 k-read
+// batch: groups of 17 k reads 69 ms, 25 k 73 ms, 33 k 78 ms.
+constexpr uint64_t EXT_GROUP_READS = 16384;
 uint64_t ext_group_subs(uint64_t sub, uint64_t nsub) {
     if (const char *e = getenv("LRM_HOST_GROUP")) { const long long v = atoll(e); if (v >= 1) return (uint64_t) v < nsub ? (uint64_t) v : nsub; }   // test knob
     const uint64_t g = (EXT_GROUP_READS + sub - 1) / (sub ? sub : 1);
@@ -302,7 +305,7 @@ struct Range { uint64_t off, m; };
 int take_errors(LrmHostCtx &c) {
     int rc = 0;
     for (int s = 0; s < N_SEED_STREAMS; ++s) if (lrm_ws_take_error(c.ws_seed[s])) rc = -2;
-    if (lrm_ws_take_error(c.ws_ext)) rc = -2;
+    for (int s = 0; s < N_EXT_STREAMS; ++s) if (lrm_ws_take_error(c.ws_ext[s])) rc = -2;
     return rc;
 }
 
@@ -397,9 +400,20 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
     std::vector<Range> subs, units;
     for (uint64_t off = 0; off < n; off += sub) subs.push_back({off, n - off < sub ? n - off : sub});
     const uint64_t gsub = (j.mode & DO_EXTEND) ? ext_group_subs(sub, subs.size()) : 1;
-    for (size_t k = 0; k < subs.size(); k += gsub) {
-        const size_t e = k + gsub < subs.size() ? k + gsub : subs.size();
-        units.push_back({subs[k].off, subs[e - 1].off + subs[e - 1].m - subs[k].off});
+    // unit boundaries (in sub-batches).  LRM_HOST_TAIL=1 cuts the last group once more (what follows the last kernel
+    // is the download of the last unit); measured: no gain, the call is bound by its kernels -- off
+    std::vector<size_t> ends;
+    for (size_t k = gsub; k < subs.size(); k += gsub) ends.push_back(k);
+    ends.push_back(subs.size());
+    {
+        const char *e = getenv("LRM_HOST_TAIL");
+        const size_t last_lo = ends.size() > 1 ? ends[ends.size() - 2] : 0;
+        if ((j.mode & DO_EXTEND) && e && atoi(e) != 0 && subs.size() - last_lo >= 2) ends.insert(ends.end() - 1, subs.size() - 1);
+    }
+    std::vector<size_t> unit_of(subs.size());
+    for (size_t g = 0, k0 = 0; g < ends.size(); k0 = ends[g], ++g) {
+        units.push_back({subs[k0].off, subs[ends[g] - 1].off + subs[ends[g] - 1].m - subs[k0].off});
+        for (size_t k = k0; k < ends[g]; ++k) unit_of[k] = g;
     }
     uint64_t unit_max = 0;
     for (auto &u : units) unit_max = u.m > unit_max ? u.m : unit_max;
@@ -407,7 +421,9 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
     if (j.mode & DO_SEED)
         for (int s = 0; s < N_SEED_STREAMS && (size_t) s < subs.size(); ++s)
             if (get_ws(c.ws_seed[s], idx, sub, max_len, j.p.seed_len, j.p.thres, LRM_WS_SEED)) return -1;
-    if ((j.mode & DO_EXTEND) && get_ws(c.ws_ext, idx, unit_max, max_len, 20, 300, LRM_WS_EXTEND)) return -1;
+    if (j.mode & DO_EXTEND)
+        for (int s = 0; s < N_EXT_STREAMS && (size_t) s < units.size(); ++s)
+            if (get_ws(c.ws_ext[s], idx, unit_max, max_len, 20, 300, LRM_WS_EXTEND)) return -1;
     if (ensure_events(c.ev_up, subs.size()) || ensure_events(c.ev_seed, subs.size()) || ensure_events(c.ev_ext, units.size())) return -1;
     DevSet &d = c.dev;
     if (d.reads.ensure(n * j.stride) || d.lens.ensure(n * 4) || d.best.ensure(n * sizeof(lrm_entry))) { lrm_set_error("device allocation failed"); return -1; }
@@ -427,7 +443,7 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
                 if (pipe.rc || pipe.issued <= g) return;
             }
             // seed-only: a unit is done when the seeds of its last sub-batch are (sub-batches of a seed stream are ordered)
-            hipEvent_t done = seed_only ? c.ev_seed[(g + 1) * gsub - 1 < subs.size() ? (g + 1) * gsub - 1 : subs.size() - 1] : c.ev_ext[g];
+            hipEvent_t done = seed_only ? c.ev_seed[ends[g] - 1] : c.ev_ext[g];
             const int rc = collect(c, j, units[g], done, dstride, clk);
             if (rc) { pipe.fail(rc); return; }
         }
@@ -452,16 +468,17 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
                                     (lrm_entry *) d.best.p + off, c.seed[s])) return -1;
                 HIPCHK(hipEventRecord(c.ev_seed[k], c.seed[s]));
             }
-            const uint64_t g = k / gsub;
-            const bool closes = (k + 1) % gsub == 0 || k + 1 == subs.size();
+            const uint64_t g = unit_of[k];
+            const bool closes = k + 1 == ends[g];
             if (closes && (j.mode & DO_EXTEND)) {                                  // the group's extension, behind its seeds / uploads
-                for (uint64_t x = g * gsub; x <= k; ++x) HIPCHK(hipStreamWaitEvent(c.ext, (j.mode & DO_SEED) ? c.ev_seed[x] : c.ev_up[x], 0));
+                const int xs = (int) (g % N_EXT_STREAMS);
+                for (uint64_t x = g ? ends[g - 1] : 0; x <= k; ++x) HIPCHK(hipStreamWaitEvent(c.ext[xs], (j.mode & DO_SEED) ? c.ev_seed[x] : c.ev_up[x], 0));
                 const Range &u = units[g];
-                if (lrm_launch_extend(idx, c.ws_ext, (char *) d.reads.p + u.off * j.stride, j.stride, (const uint32_t *) d.lens.p + u.off, u.m,
+                if (lrm_launch_extend(idx, c.ws_ext[xs], (char *) d.reads.p + u.off * j.stride, j.stride, (const uint32_t *) d.lens.p + u.off, u.m,
                                       max_len, (const lrm_entry *) d.best.p + u.off, j.gp, (uint8_t *) d.store.p + u.off * dstride, dstride,
                                       (int32_t *) d.nops.p + u.off, (int32_t *) d.score.p + u.off, (lrm_seq_meta *) d.meta.p + u.off,
-                                      (int32_t *) d.mr.p + u.off, c.ext)) return -1;
-                HIPCHK(hipEventRecord(c.ev_ext[g], c.ext));
+                                      (int32_t *) d.mr.p + u.off, c.ext[xs])) return -1;
+                HIPCHK(hipEventRecord(c.ev_ext[g], c.ext[xs]));
             }
             if (closes) {
                 { std::lock_guard<std::mutex> lk(pipe.m); pipe.issued = g + 1; }
@@ -480,7 +497,8 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
     if (clk.on) fprintf(stderr, "[lrm host] slice of %llu reads, %zu seed sub-batches, %zu units: %.1f ms\n", (unsigned long long) n, subs.size(), units.size(), clk.ms());
     if (pipe.rc) {
         for (int s = 0; s < N_SEED_STREAMS; ++s) (void) hipStreamSynchronize(c.seed[s]);
-        (void) hipStreamSynchronize(c.ext); (void) hipStreamSynchronize(c.up); (void) hipStreamSynchronize(c.down);
+        for (int s = 0; s < N_EXT_STREAMS; ++s) (void) hipStreamSynchronize(c.ext[s]);
+        (void) hipStreamSynchronize(c.up); (void) hipStreamSynchronize(c.down);
         (void) take_errors(c);                                        // reported now: do not fail the next call
         lrm_set_error("%s", pipe.err);
         return pipe.rc;
@@ -555,17 +573,19 @@ void lrm_host_ctx_free(lrm_index *idx) {
     idx->host = nullptr;
     if (c->ready) {
         for (int s = 0; s < N_SEED_STREAMS; ++s) (void) hipStreamSynchronize(c->seed[s]);
-        (void) hipStreamSynchronize(c->ext); (void) hipStreamSynchronize(c->up); (void) hipStreamSynchronize(c->down);
+        for (int s = 0; s < N_EXT_STREAMS; ++s) (void) hipStreamSynchronize(c->ext[s]);
+        (void) hipStreamSynchronize(c->up); (void) hipStreamSynchronize(c->down);
         for (int b = 0; b < 2; ++b) {
             (void) hipHostFree(c->pin_up[b]); (void) hipHostFree(c->pin_dn[b]);
             (void) hipEventDestroy(c->ev_pin_up[b]); (void) hipEventDestroy(c->ev_pin_dn[b]);
         }
-        (void) hipStreamDestroy(c->up); (void) hipStreamDestroy(c->down); (void) hipStreamDestroy(c->ext);
+        (void) hipStreamDestroy(c->up); (void) hipStreamDestroy(c->down);
+        for (int s = 0; s < N_EXT_STREAMS; ++s) (void) hipStreamDestroy(c->ext[s]);
         for (int s = 0; s < N_SEED_STREAMS; ++s) (void) hipStreamDestroy(c->seed[s]);
     }
     for (auto *v : {&c->ev_up, &c->ev_seed, &c->ev_ext}) for (hipEvent_t e : *v) (void) hipEventDestroy(e);
     for (int s = 0; s < N_SEED_STREAMS; ++s) if (c->ws_seed[s]) lrm_workspace_free(c->ws_seed[s]);
-    if (c->ws_ext) lrm_workspace_free(c->ws_ext);
+    for (int s = 0; s < N_EXT_STREAMS; ++s) if (c->ws_ext[s]) lrm_workspace_free(c->ws_ext[s]);
     DevSet &d = c->dev;
     d.reads.release(); d.lens.release(); d.best.release(); d.store.release();
     d.nops.release(); d.score.release(); d.meta.release(); d.mr.release(); d.dense.release(); d.offs.release();
