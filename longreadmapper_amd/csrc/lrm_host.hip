@@ -25,6 +25,7 @@
 #include <cstring>
 #include <chrono>
 #include <condition_variable>
+#include <exception>
 #include <mutex>
 #include <new>
 #include <string>
@@ -427,8 +428,11 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
     if (ensure_events(c.ev_up, subs.size()) || ensure_events(c.ev_seed, subs.size()) || ensure_events(c.ev_ext, units.size())) return -1;
     DevSet &d = c.dev;
     if (d.reads.ensure(n * j.stride) || d.lens.ensure(n * 4) || d.best.ensure(n * sizeof(lrm_entry))) { lrm_set_error("device allocation failed"); return -1; }
+    // (the dense result buffer and its offset table at their worst-case size for a unit, so that the download thread
+    //  never reallocates -- a hipFree would drain the whole device -- while other units are in flight)
     if ((j.mode & DO_EXTEND) && (d.store.ensure(n * dstride) || d.nops.ensure(n * 4) || d.score.ensure(n * 4) ||
-                                  d.meta.ensure(n * sizeof(lrm_seq_meta)) || d.mr.ensure(n * 4))) { lrm_set_error("device allocation failed"); return -1; }
+                                  d.meta.ensure(n * sizeof(lrm_seq_meta)) || d.mr.ensure(n * 4) ||
+                                  d.dense.ensure(unit_max * (dstride + j.stride + 32)) || d.offs.ensure(unit_max * 2 * 12))) { lrm_set_error("device allocation failed"); return -1; }
 
     Pipe pipe;
     HostClock clk;
@@ -444,7 +448,9 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
             }
             // seed-only: a unit is done when the seeds of its last sub-batch are (sub-batches of a seed stream are ordered)
             hipEvent_t done = seed_only ? c.ev_seed[ends[g] - 1] : c.ev_ext[g];
-            const int rc = collect(c, j, units[g], done, dstride, clk);
+            int rc;
+            try { rc = collect(c, j, units[g], done, dstride, clk); }
+            catch (const std::exception &e) { lrm_set_error("download thread: %s", e.what()); rc = -1; }
             if (rc) { pipe.fail(rc); return; }
         }
     });
@@ -507,11 +513,16 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
     return 0;
 }
 
+std::mutex g_host_ctx_init;             // creation of a handle's host context (the context's own mutex lives inside it)
+
 int run_replica(lrm_index *idx, const MapJob &j) {
     if (lrm_require_device(idx->device)) return -1;
-    if (!idx->host) {
-        idx->host = new (std::nothrow) LrmHostCtx;
-        if (!idx->host) { lrm_set_error("out of memory"); return -1; }
+    {
+        std::lock_guard<std::mutex> g(g_host_ctx_init);
+        if (!idx->host) {
+            idx->host = new (std::nothrow) LrmHostCtx;
+            if (!idx->host) { lrm_set_error("out of memory"); return -1; }
+        }
     }
     LrmHostCtx &c = *idx->host;
     std::lock_guard<std::mutex> g(c.mu);
@@ -542,7 +553,21 @@ void partition_by_bases(const uint32_t *lens, uint64_t n, int parts, std::vector
     }
 }
 
+int run_job_impl(lrm_index *idx, const MapJob &j);
+// C ABI: no C++ exception may leave the library (allocation failures of the host-side bookkeeping, thread creation)
 int run_job(lrm_index *idx, const MapJob &j) {
+    try {
+        return run_job_impl(idx, j);
+    } catch (const std::exception &e) {
+        lrm_set_error("host-side failure: %s", e.what());
+        return -1;
+    } catch (...) {
+        lrm_set_error("host-side failure");
+        return -1;
+    }
+}
+
+int run_job_impl(lrm_index *idx, const MapJob &j) {
     if (j.n == 0) return 0;
     if (idx->n_peers <= 1 || !idx->peers) return run_replica(idx, j);
     const int np = idx->n_peers;

@@ -276,7 +276,9 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
     // (independent chains per lane, all rank gathers of a step in flight at once: 43.4 / 56.7 ms per step against
     // 29.0 [r2]): a wavefront of one-seed lanes stops as soon as its 64 neighbouring seeds are dead, a wavefront of
     // interleaved chains runs until its longest chain ends, and 7.4 G wave-instructions of 64-bit index arithmetic
-    // per Gbp are a third of the kernel's time -- it is not bound by memory latency alone.
+    // per Gbp are a third of the kernel's time -- it is not bound by memory latency alone.  Also measured [r2]: a
+    // 2 MiB presence bitmap of the 12-mers in front of the table lookup (57 % of the seeds die on an L2 hit instead of
+    // fetching a table line): 27.3 vs 27.5 ms, not kept; non-temporal loads for the one-touch table lines: 31.7 ms.
     const uint32_t len = lens[read];
     const uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;   // alnmain.c:353 (fenced for len<s)
     const uint64_t *words = reads2 + read * words_per_read;
@@ -343,6 +345,8 @@ __global__ __launch_bounds__(256) void seed_search_debug_kernel(LrmIndexView ix,
 // of its first hit, which is intrinsic to the hit -- so the table can be filled in any order: every slot keeps the
 // count, the low 4 bits of the minimum key and the minimum order key (q << tbits) | t.
 //
+// (Measured and not kept [r2]: a second kernel with a 4096-slot table (70 KB of LDS) for items that need three or more
+//  passes -- ultra-long reads, ~3500 hits per item: 45.0 vs 46.1 ms per 2 Gbp, 10.9 vs 11.2 on the bench workload.)
 // The vote table always lives in LDS.  ONE kernel votes every (read, phase) item; a 256-thread workgroup owns
 // VG consecutive items and routes each by its hit count H (an upper bound on its distinct buckets, left by
 // seed_search next to the survivor list):

@@ -224,3 +224,34 @@ def test_rccl_is_loadable_and_bound(gpu):
     256 MiB pieces, ncclCommDestroy."""
     rc = capi.lib.lrm_debug_rccl_selftest(gpu, (300 << 20) + 12345)
     assert rc == 0, (rc, capi.lib.lrm_last_error())
+
+
+def test_concurrent_calls_on_one_handle_and_on_two(ont, gpu):
+    """"re-entrant per handle, no hidden globals".  Four host threads call lrm_map_batch at the same
+    time -- two on one handle (serialised by the handle's own mutex), one each on two more handles (independent) --
+    and every call returns the single-threaded result."""
+    import threading
+    sc, di, oi, best, ext, r_cpu = ont
+    others = [index.DeviceIndex.upload(sc["hi"], gpu) for _ in range(2)]
+    out, errs = {}, []
+
+    def work(tag, handle):
+        try:
+            for rep in range(3):
+                r = sc["reads"].copy()
+                got = mapper.map_batch(handle, r, sc["lens"], sc["seed_len"], sc["thres"])
+                assert np.array_equal(got["best"], best) and np.array_equal(r, r_cpu)
+                _assert_ext_equal(got, ext, len(best), tag)
+            out[tag] = True
+        except Exception as e:          # noqa: BLE001 -- reported below with the thread's tag
+            errs.append((tag, repr(e)))
+
+    th = [threading.Thread(target=work, args=(t, h)) for t, h in (("a0", di), ("a1", di), ("b", others[0]), ("c", others[1]))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for o in others:
+        o.close()
+    assert not errs, errs
+    assert len(out) == 4
