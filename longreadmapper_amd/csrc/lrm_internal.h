@@ -152,7 +152,8 @@ struct lrm_workspace {
     uint8_t *d_decided;      // n_max
     uint32_t *d_hcount;      // SA hits (sum of rr) per (read, phase): routes an item to its vote-table tier
     LrmDevCounters *d_counters;
-    volatile uint32_t *h_err;   // error word (pinned host memory) and its device alias
+    uint64_t hist_n;         // reads of the last seed launch (with the phase-0 decision count at h_err + 2: round policy)
+    volatile uint32_t *h_err;   // error word (pinned host memory, 64 B block) and its device alias
     uint32_t *d_err;
     // bit-sliced GACT: planar reads (wpr words per read) and per-read "byte other than ACGT" flags
     uint64_t *d_qpl;

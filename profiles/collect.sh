@@ -29,7 +29,7 @@ elif [ "$PART" = "B" ]; then
                 "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_ADDR_CONFLICT"; do
         tag=$(echo $pass | cut -d" " -f1)
         timeout -k 10 200 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$tag -- \
-            python3 $GRAFT_REPO_ROOT/bench.py --streams 1 --steps 1 --warmup 1 --cpu-seconds 0 --no-kernel-timing --no-pcie --no-isolated-replay \
+            python3 $GRAFT_REPO_ROOT/bench.py --streams 1 --steps 1 --warmup 2 --cpu-seconds 0 --no-kernel-timing --no-pcie --no-isolated-replay \
             > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.err || exit 1
         echo "pmc $tag done"
     done

@@ -31,6 +31,11 @@ if stats:
     shutil.copy(stats[0], os.path.join(dst, "kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, "bench_default.json"))
 
+_b = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
+for _k, _v in (_b.get("isolated") or {}).get("kernels", {}).items():       # launches per step as the library really ran them
+    if _k in LAUNCHES_PER_STEP and _b.get("steps"):
+        LAUNCHES_PER_STEP[_k] = max(1, round(_v["launches"] / _b["steps"]))
+
 per_kernel = collections.defaultdict(dict)
 for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
     rows = list(csv.DictReader(open(f)))

@@ -379,3 +379,19 @@ def test_long_interval_side_table(gpu, monkeypatch):
     got = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
     assert np.array_equal(got, want)
     di.close()
+
+
+@pytest.mark.parametrize("name", ["clean-1k", "ont-2k", "last-phase-break", "ragged"])
+def test_round_policy_does_not_change_results(dev_indexes, monkeypatch, name):
+    """Phase 0 first and phases 1..s for the undecided reads (two rounds), or all phases at once (what the library
+    switches to when the previous batch decided almost nothing in phase 0): same best[], because evaluating phases
+    speculatively and replaying alnmain.c:371-403 in order is exact."""
+    sc, di, oi = dev_indexes(name)
+    want, _ = oi.seed_batch(sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+    for rounds in ("2", "1", "2"):
+        monkeypatch.setenv("LRM_SEED_ROUNDS", rounds)
+        got = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+        assert np.array_equal(got, want), (name, rounds)
+    monkeypatch.delenv("LRM_SEED_ROUNDS")
+    for _ in range(3):                     # the adaptive policy: the second and third call see the first one's history
+        assert np.array_equal(mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"]), want)
