@@ -91,14 +91,7 @@ __device__ __forceinline__ uint64_t c4_of(const LrmIndexView &ix, uint32_t c) {
 // (fmidx.c:323, `- 1` on top of the inclusive rank: its walk leaves the text order and gives up after 5*ratio
 // steps); this is the textbook LF, so that the locate equals sa_access on every row -- the two modes of this
 // library give identical results, and csa_access itself is never called on the reference's hot path.
-#ifndef LRM_VOTE_PROBE
-#define LRM_VOTE_PROBE 0          // tuning builds only (tools/build_probe.py): 1 = no SA gather, 2 = no table inserts,
-                                  // 4 = slot claims only
-#endif
 __device__ __forceinline__ uint64_t sa_locate(const LrmIndexView &ix, uint64_t row) {
-#if LRM_VOTE_PROBE == 1
-    return row * 977ull;
-#endif
     if (ix.sa_shift == 0) return ix.sa[row];
     const uint64_t rmask = (1ull << ix.sa_shift) - 1ull;
     uint64_t t = 0;
@@ -398,11 +391,9 @@ __device__ __forceinline__ bool vote_insert(const VoteTable &t, uint64_t key, ui
         //  13.4 ms per Gbp [r2] -- the extra dependent LDS round trip costs more than the CAS it saves)
         const unsigned long long prev = atomicCAS((unsigned long long *) &t.key[slot], EMPTY_KEY, key);
         if (prev == EMPTY_KEY || (prev >> 4) == bucket) {
-#if LRM_VOTE_PROBE != 4          // (tuning build 4: the slot claim alone)
             if (prev != EMPTY_KEY && key < prev) atomicMin((unsigned long long *) &t.key[slot], (unsigned long long) key);
             atomicAdd(&t.count[slot], n);
             atomicMin(&t.first[slot], order);
-#endif
             return true;
         }
         slot = slot + 1 == t.slots ? 0 : slot + 1;
@@ -411,9 +402,6 @@ __device__ __forceinline__ bool vote_insert(const VoteTable &t, uint64_t key, ui
 }
 
 __device__ __forceinline__ bool vote_admit(const VoteTable &t, uint64_t key, uint32_t order, uint32_t passes, uint32_t pass) {
-#if LRM_VOTE_PROBE == 2
-    return key != 0x123456789ull;
-#endif
     const uint32_t hash = bucket_hash(key >> 4);
     if (passes == 1 || (hash >> 16) % passes == pass) return vote_insert(t, key, order, hash);
     return true;

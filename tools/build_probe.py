@@ -1,6 +1,8 @@
-"""Tuning builds of liblrm_accel.so with a compile-time probe switched on (NOT the shipped library: results are
-wrong by construction).  python tools/build_probe.py 1 2  ->  gpurun_out/probe_libs/liblrm_accel_vp1.so ...
-Use with LRM_ACCEL_LIB=<path> python tools/seed_probe.py"""
+"""Tuning builds of liblrm_accel.so with compile-time knobs (-D defines), next to the shipped library:
+  python tools/build_probe.py LRM_VOTE_T3_SLOTS=768 LRM_VOTE_WAVES_PER_EU=5  ->  tools/_probe_libs/liblrm_accel_<define>.so
+Use with LRM_ACCEL_LIB=<path> python tools/seed_probe.py.  (Round 2 also used throw-away probe builds that skipped the
+SA gathers / the table inserts to see where the vote kernel's time goes; their outputs are under profiles/r2/probes/,
+the switches were removed from the product source afterwards.)"""
 import os
 import sys
 
@@ -14,5 +16,4 @@ for v in sys.argv[1:]:
         p = os.path.join(out, "liblrm_accel_%s.so" % v.replace("=", "_"))
         print(_build.build_accel(force=True, defines=[v], out=p))
     else:
-        p = os.path.join(out, "liblrm_accel_vp%s.so" % v)
-        print(_build.build_accel(force=True, defines=["LRM_VOTE_PROBE=" + v], out=p))
+        raise SystemExit("expected NAME=VALUE")
