@@ -119,6 +119,8 @@ struct LrmDevCounters {
 #define LRM_VOTE_T3_SLOTS 1024
 #endif
 #define LRM_VOTE_T3_LIMIT (LRM_VOTE_T3_SLOTS * 3 / 4)
+#define LRM_VOTE_GRID 1536        // resident workgroups of the vote kernel (6 per CU)
+#define LRM_VOTE_KC_CAP 16384     // hits per workgroup whose keys the multi-pass items keep between passes (12 B each)
 
 enum LrmKernelId { LRM_K_PACK2BIT = 0, LRM_K_SEED_SEARCH, LRM_K_VOTE, LRM_K_DECIDE,
                    LRM_K_LOCUS, LRM_K_REVCOMP, LRM_K_GACT, LRM_K_PACK_PLANAR, LRM_K_GACT_BS,
@@ -148,6 +150,8 @@ struct lrm_workspace {
     uint64_t *d_rec;         // survivor records k | rr << 40, compact per (read, phase): n_max * P * cap_q capacity
     uint32_t *d_recq;        // seed ordinal q of every survivor record
     uint32_t *d_cnt;         // survivors per (read, phase)
+    uint64_t *d_kc_key;      // vote kernel: per-workgroup scratch of the keys of multi-pass items (LRM_VOTE_GRID x LRM_VOTE_KC_CAP)
+    uint32_t *d_kc_ord;      //              ... and their order keys
     LrmPhaseRes *d_phase;    // n_max * P
     uint8_t *d_decided;      // n_max
     uint32_t *d_hcount;      // SA hits (sum of rr) per (read, phase): routes an item to its vote-table tier

@@ -496,7 +496,7 @@ template <int NT, int VOTE_U>               // VOTE_U: SA gathers in flight per 
 __device__ __forceinline__ bool vote_hits(const LrmIndexView &ix, const VoteTable &t, const uint32_t *off,
                                           const uint64_t *srec, const uint32_t *sq, uint32_t cnt, uint32_t total,
                                           uint32_t iter, uint32_t P, uint32_t tbits, uint32_t tid, uint32_t passes,
-                                          uint32_t pass) {
+                                          uint32_t pass, uint64_t *kc_key = nullptr, uint32_t *kc_ord = nullptr) {
     bool ok = true;
     for (uint32_t hb = 0; hb < total; hb += NT * VOTE_U) {
         uint64_t v[VOTE_U];
@@ -518,6 +518,7 @@ __device__ __forceinline__ bool vote_hits(const LrmIndexView &ix, const VoteTabl
             if (h < total) {
                 const uint32_t q = sq[ss[u]];
                 const uint64_t key = v[u] - (uint64_t) (iter + q * P);              // alnmain.c:363-365 (u64 wrap kept); j < 2^32
+                if (kc_key) { kc_key[h] = key; kc_ord[h] = (q << tbits) | tt[u]; }   // multi-pass items: keys kept for the later passes
                 ok &= vote_admit(t, key, (q << tbits) | tt[u], passes, pass);
             }
         }
@@ -606,11 +607,16 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
                                                 const uint32_t *__restrict__ recq, uint32_t cnt, uint32_t H,
                                                 uint32_t iter, uint32_t P, uint32_t tbits, uint32_t slots, uint32_t limit,
                                                 BlockLds &L, uint32_t *s_wsum, Top2 *s_top, LrmPhaseRes *out,
-                                                uint32_t *err_word, uint32_t load) {
+                                                uint32_t *err_word, uint32_t load, uint64_t *kc_key, uint32_t *kc_ord,
+                                                uint32_t kc_cap) {
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     const int lane = (int) (tid & 63);
     VoteTable t = {L.key, L.count, L.first, slots};
     const uint32_t passes = (H + limit - 1) / limit;
+    // Items that need several passes (ultra-long reads: ~3500 hits, five passes): the first pass writes every hit's
+    // {key, order key} to this workgroup's slice of a global scratch, and the later passes stream them back
+    // (12 coalesced bytes per hit) instead of searching, gathering and subtracting again.
+    const bool cache = passes > 1 && H <= kc_cap;
     {
         const uint32_t per_pass = passes > 1 ? limit : H;
         const uint32_t eff = per_pass * 100u / load + 64;
@@ -620,6 +626,11 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
     for (uint32_t pass = 0; pass < passes; ++pass) {
         for (uint32_t s = tid; s < t.slots; s += 256) { t.key[s] = EMPTY_KEY; t.count[s] = 0; t.first[s] = EMPTY32; }
         bool ok = true;
+        if (cache && pass > 0) {
+            __syncthreads();                                   // table cleared
+            for (uint32_t i = tid; i < H; i += 256) ok &= vote_admit(t, kc_key[i], kc_ord[i], passes, pass);
+        } else {
+        uint32_t kbase = 0;                                    // hits of the chunks before this one
         for (uint32_t c0 = 0; c0 < cnt; c0 += T3_CHUNK) {
             const uint32_t nc = cnt - c0 < (uint32_t) T3_CHUNK ? cnt - c0 : (uint32_t) T3_CHUNK;
             // one survivor per thread; unique seeds gather at once, repeat seeds are compacted into LDS
@@ -628,17 +639,17 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
             const uint32_t r0 = (uint32_t) (e0 >> 40);
             const uint64_t v0 = r0 == 1 ? sa_locate(ix, e0 & ((1ull << 40) - 1ull)) : 0ull;
             const uint32_t b0 = r0 > 1 ? 1u : 0u, h0 = b0 ? r0 : 0u;
-            const unsigned long long bm = __ballot(b0 != 0);
+            const unsigned long long bm = __ballot(b0 != 0), um = __ballot(r0 == 1);
             const uint32_t incl_h = wave_incl_scan(h0);
             __syncthreads();                                   // the previous chunk's (or pass's) staging is no longer read
-            if (lane == 63) { s_wsum[wave] = incl_h; s_wsum[4 + wave] = (uint32_t) __popcll(bm); }
+            if (lane == 63) { s_wsum[wave] = incl_h; s_wsum[4 + wave] = (uint32_t) __popcll(bm); s_wsum[8 + wave] = (uint32_t) __popcll(um); }
             __syncthreads();
-            uint32_t woff_h = 0, total = 0, woff_n = 0, nbig = 0;
+            uint32_t woff_h = 0, total = 0, woff_n = 0, nbig = 0, woff_u = 0, nuni = 0;
 #pragma unroll
             for (uint32_t w = 0; w < 4; ++w) {
-                const uint32_t x = s_wsum[w], y = s_wsum[4 + w];
-                total += x; nbig += y;
-                if (w < wave) { woff_h += x; woff_n += y; }
+                const uint32_t x = s_wsum[w], y = s_wsum[4 + w], z = s_wsum[8 + w];
+                total += x; nbig += y; nuni += z;
+                if (w < wave) { woff_h += x; woff_n += y; woff_u += z; }
             }
             if (b0) {
                 const uint32_t idx = woff_n + mask_rank(bm);
@@ -646,8 +657,16 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
             }
             if (tid == 0) L.off[nbig] = total;
             __syncthreads();
-            if (r0 == 1) ok &= vote_admit(t, v0 - (uint64_t) (iter + q0 * P), q0 << tbits, passes, pass);
-            if (nbig) ok &= vote_hits<256, VOTE_U>(ix, t, L.off, L.srec, L.sq, nbig, total, iter, P, tbits, tid, passes, pass);
+            if (r0 == 1) {
+                const uint64_t key = v0 - (uint64_t) (iter + q0 * P);
+                if (cache) { const uint32_t i = kbase + woff_u + mask_rank(um); kc_key[i] = key; kc_ord[i] = q0 << tbits; }
+                ok &= vote_admit(t, key, q0 << tbits, passes, pass);
+            }
+            if (nbig) ok &= vote_hits<256, VOTE_U>(ix, t, L.off, L.srec, L.sq, nbig, total, iter, P, tbits, tid, passes, pass,
+                                                   cache ? kc_key + kbase + nuni : nullptr, cache ? kc_ord + kbase + nuni : nullptr);
+            kbase += nuni + total;
+        }
+        if (cache) __threadfence_block();                      // the scratch is read back by other threads of the workgroup
         }
         if (!ok) *(volatile uint32_t *) err_word = LRM_ERR_VOTE_OVERFLOW;   // host-coherent, sticky
         __syncthreads();
@@ -702,19 +721,32 @@ void vote_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
                                                    const uint8_t *__restrict__ decided, uint64_t n, int seed_len,
                                                    int phase_lo, int phase_hi, uint32_t cap_q, uint32_t tbits,
                                                    uint32_t slots3, uint32_t limit3, uint32_t vg, uint32_t limit1, uint32_t load,
+                                                   unsigned long long *ticket, uint64_t *__restrict__ kc_key_all,
+                                                   uint32_t *__restrict__ kc_ord_all, uint32_t kc_cap,
                                                    LrmPhaseRes *__restrict__ phase_res, uint32_t *err_word) {
     __shared__ VoteLds lds;
     __shared__ uint32_t g_H[VG_MAX], g_cnt[VG_MAX];
     __shared__ uint64_t g_id[VG_MAX];
-    __shared__ uint32_t s_wsum[8];
+    __shared__ uint32_t s_wsum[12];
     __shared__ Top2 s_top[4];
+    __shared__ unsigned long long s_grp;
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     const int lane = (int) (tid & 63);
     const uint32_t P = (uint32_t) seed_len + 1;
     const uint32_t np = (uint32_t) (phase_hi - phase_lo + 1);
     const uint64_t n_items = n * (uint64_t) np;
+    const uint64_t n_groups = (n_items + vg - 1) / vg;
+    uint64_t *kc_key = kc_key_all + (uint64_t) blockIdx.x * kc_cap;      // this workgroup's slice of the key scratch
+    uint32_t *kc_ord = kc_ord_all + (uint64_t) blockIdx.x * kc_cap;
+    // A fixed grid of resident workgroups takes groups of items from a ticket counter (dynamic balance, and one
+    // scratch slice per workgroup); every workgroup ends with a ticket beyond the last group.
+    for (;;) {
+    if (tid == 0) s_grp = atomicAdd(ticket, 1ull);
+    __syncthreads();
+    const uint64_t grp = s_grp;
+    if (grp >= n_groups) break;
     if (tid < vg) {
-        const uint64_t item = (uint64_t) blockIdx.x * vg + tid;
+        const uint64_t item = grp * vg + tid;
         uint32_t H = 0, c = 0;
         uint64_t id = 0;
         if (item < n_items) {
@@ -742,8 +774,10 @@ void vote_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
         if (H <= limit1) continue;
         const uint64_t id = g_id[g];
         vote_item_block<VOTE_U>(ix, rec + id * cap_q, recq + id * cap_q, g_cnt[g], H, (uint32_t) (id % P), P, tbits, slots3,
-                        limit3, lds.b, s_wsum, s_top, &phase_res[id], err_word, load);
+                        limit3, lds.b, s_wsum, s_top, &phase_res[id], err_word, load, kc_key, kc_ord, kc_cap);
         __syncthreads();
+    }
+    __syncthreads();                                          // s_grp, g_* are rewritten by the next round
     }
 }
 
@@ -899,12 +933,13 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
         lrm_time_end(ws, stream);
         uint64_t items = n * (uint64_t) np;
         uint64_t vblocks = (items + vg - 1) / vg;
-        if (vblocks > 0x7fffffffull) { lrm_set_error("vote grid too large: split the batch"); return -1; }
+        if (vblocks > LRM_VOTE_GRID) vblocks = LRM_VOTE_GRID;          // resident workgroups; groups of items go by ticket
         lrm_time_begin(ws, LRM_K_VOTE, stream);
         auto vk = vote_u == 2 ? vote_kernel<2> : vote_u == 8 ? vote_kernel<8> : vote_kernel<4>;
         hipLaunchKernelGGL(vk, dim3((uint32_t) vblocks), dim3(256), 0, stream, idx->view, ws->d_rec, ws->d_recq,
                            ws->d_cnt, ws->d_hcount, dec, n, (int) seed_len, lo, hi, cap_q, tbits, t3_slots, t3_limit,
-                           vg, t1_limit, vote_load, ws->d_phase, ws->d_err);
+                           vg, t1_limit, vote_load, &ws->d_counters->reserved[1 + round], ws->d_kc_key, ws->d_kc_ord,
+                           (uint32_t) LRM_VOTE_KC_CAP, ws->d_phase, ws->d_err);
         lrm_time_end(ws, stream);
         lrm_time_begin(ws, LRM_K_DECIDE, stream);
         hipLaunchKernelGGL(decide_kernel, dim3((uint32_t) ((n + 255) / 256)), dim3(256), 0, stream, ws->d_phase,
