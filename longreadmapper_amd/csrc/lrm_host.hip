@@ -401,16 +401,11 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
     std::vector<Range> subs, units;
     for (uint64_t off = 0; off < n; off += sub) subs.push_back({off, n - off < sub ? n - off : sub});
     const uint64_t gsub = (j.mode & DO_EXTEND) ? ext_group_subs(sub, subs.size()) : 1;
-    // unit boundaries (in sub-batches).  LRM_HOST_TAIL=1 cuts the last group once more (what follows the last kernel
-    // is the download of the last unit); measured: no gain, the call is bound by its kernels -- off
+    // unit boundaries (in sub-batches).  (Cutting the last group once more, so that less is left to download after
+    // the last kernel, was measured: no gain -- the call is bound by its kernels.)
     std::vector<size_t> ends;
     for (size_t k = gsub; k < subs.size(); k += gsub) ends.push_back(k);
     ends.push_back(subs.size());
-    {
-        const char *e = getenv("LRM_HOST_TAIL");
-        const size_t last_lo = ends.size() > 1 ? ends[ends.size() - 2] : 0;
-        if ((j.mode & DO_EXTEND) && e && atoi(e) != 0 && subs.size() - last_lo >= 2) ends.insert(ends.end() - 1, subs.size() - 1);
-    }
     std::vector<size_t> unit_of(subs.size());
     for (size_t g = 0, k0 = 0; g < ends.size(); k0 = ends[g], ++g) {
         units.push_back({subs[k0].off, subs[ends[g] - 1].off + subs[ends[g] - 1].m - subs[k0].off});
