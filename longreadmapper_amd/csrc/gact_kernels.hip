@@ -60,57 +60,94 @@ __global__ __launch_bounds__(256) void locus_resolve_kernel(LrmIndexView ix, con
     meta_r[read] = mr;
 }
 
-__device__ __forceinline__ char comp_base(char c) {           // alnmain.c:31-52
-    switch (c) {
-        case 'A': case 'a': return 'T';
-        case 'C': case 'c': return 'G';
-        case 'G': case 'g': return 'C';
-        case 'T': case 't': return 'A';
-        default: return 'N';
-    }
+// alnmain.c:31-52: A/a -> T, C/c -> G, G/g -> C, T/t -> A, anything else -> N.  Branch-free on purpose: a `switch`
+// compiles to a cascade of divergent branches per byte (the first revcomp kernel spent 1.5 ms per Gbp in them).
+__device__ __forceinline__ char comp_base(char c) {
+    const uint32_t u = (uint32_t) (uint8_t) c & 0xDFu;            // fold case
+    uint32_t r = 'N';
+    r = u == 'A' ? 'T' : r;
+    r = u == 'C' ? 'G' : r;
+    r = u == 'G' ? 'C' : r;
+    r = u == 'T' ? 'A' : r;
+    return (char) r;
+}
+
+__device__ __forceinline__ uint32_t bytes_equal(uint32_t x, uint32_t c4) {     // 0xFF in every byte of x equal to c4's
+    const uint32_t z = x ^ c4;
+    const uint32_t t = ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z | 0x7F7F7F7Fu);  // 0x80 where the byte of z is zero
+    return (t >> 7) * 0xFFu;
 }
 
 __device__ __forceinline__ uint32_t revcomp4(uint32_t w) {       // 4 bases: reversed and complemented
-    uint32_t o = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o |= (uint32_t) (uint8_t) comp_base((char) (w >> (8 * (3 - e)))) << (8 * e);
-    return o;
+    const uint32_t x = w & 0xDFDFDFDFu;
+    const uint32_t a = bytes_equal(x, 0x41414141u), c = bytes_equal(x, 0x43434343u);
+    const uint32_t g = bytes_equal(x, 0x47474747u), t = bytes_equal(x, 0x54545454u);
+    const uint32_t o = (a & 0x54545454u) | (c & 0x47474747u) | (g & 0x43434343u) | (t & 0x41414141u) |
+                       (~(a | c | g | t) & 0x4E4E4E4Eu);
+    return __builtin_bswap32(o);
 }
 
-// One thread per 4 bases of the front half and their 4 mirror bases (two 4-byte loads, two 4-byte stores; rows
-// start at any byte, the hardware handles the unaligned dwords); the < 8 bases left in the middle go bytewise.
+// In place, with ALIGNED 16-byte accesses only (rows start at any byte: stride = max_read_len + 1).  A workgroup owns
+// `seg` bases of the front half of a read and their mirror bases; it copies both spans into LDS with aligned
+// 16-byte loads (the first and last chunk reach a few bytes outside the span: loaded, never used), and after the
+// barrier every thread builds whole aligned 16-byte chunks of each span from the other one (five LDS dwords,
+// v_alignbyte, byte swap + complement).  Chunks that straddle a span's ends are written bytewise.  Measured [r2]:
+// one unaligned dword per thread 1.5 ms per Gbp, one unaligned 16-byte access per thread 2.2 ms, this version
+// see profiles/r2.
+#define RC_SEG 4096
+__device__ __forceinline__ void revcomp_span(const uint8_t *__restrict__ src, uint32_t src_off, char *gdst,
+                                             uint32_t dst_off, uint32_t cnt, uint32_t tid) {
+    // destination bytes i in [0, cnt) live at gdst_aligned + dst_off + i; byte i = comp(src[src_off + cnt-1-i])
+    const uint32_t nchunk = (dst_off + cnt + 15) / 16;
+    const uint32_t *src32 = reinterpret_cast<const uint32_t *>(src);
+    for (uint32_t c = tid; c < nchunk; c += 256) {
+        const int32_t i0 = (int32_t) (16 * c) - (int32_t) dst_off;           // first destination byte of the chunk
+        if (i0 >= 0 && (uint32_t) i0 + 16 <= cnt) {
+            const uint32_t lo = src_off + cnt - 16 - (uint32_t) i0;          // source bytes [lo, lo + 16)
+            const uint32_t q = lo >> 2, sh = lo & 3;
+            uint32_t d[5], o[4];
+#pragma unroll
+            for (int e = 0; e < 5; ++e) d[e] = src32[q + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[3 - e] = revcomp4(__builtin_amdgcn_alignbyte(d[e + 1], d[e], sh));
+            *reinterpret_cast<uint4 *>(gdst + 16 * c) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+            for (int k = 0; k < 16; ++k) {
+                const int32_t i = i0 + k;
+                if (i >= 0 && (uint32_t) i < cnt) gdst[16 * c + k] = comp_base((char) src[src_off + cnt - 1 - (uint32_t) i]);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void revcomp_kernel(char *__restrict__ reads, uint64_t stride,
                                                       const uint32_t *__restrict__ lens,
                                                       const lrm_seq_meta *__restrict__ meta,
                                                       const int32_t *__restrict__ meta_r, uint64_t n,
-                                                      uint32_t chunks_per_read) {
-    uint64_t read = blockIdx.x / chunks_per_read;
-    uint32_t chunk = blockIdx.x % chunks_per_read;
+                                                      uint32_t chunks_per_read, uint32_t seg) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_a[RC_SEG + 48], s_b[RC_SEG + 48];
+    const uint64_t read = blockIdx.x / chunks_per_read;
+    const uint32_t chunk = blockIdx.x % chunks_per_read;
     if (read >= n) return;
     if (!meta_r[read] || meta[read].strand != 1) return;       // alnmain.c:433
-    const uint32_t len = lens[read];
-    const uint32_t t = chunk * 256 + threadIdx.x;
-    const uint32_t nfull = len / 8;
+    const uint32_t len = lens[read], half = len / 2;
     char *r = reads + read * stride;
-    if (t < nfull) {
-        uint32_t a, b;
-        __builtin_memcpy(&a, r + 4 * t, 4);
-        __builtin_memcpy(&b, r + (len - 4 - 4 * t), 4);
-        const uint32_t fa = revcomp4(b), fb = revcomp4(a);
-        __builtin_memcpy(r + 4 * t, &fa, 4);
-        __builtin_memcpy(r + (len - 4 - 4 * t), &fb, 4);
-    } else if (t == nfull) {
-        uint32_t x = 4 * nfull, y = len - 4 * nfull;             // [x, y): len % 8 bases
-        while (x < y) {
-            --y;
-            const char cx = comp_base(r[x]);
-            if (x == y) { r[x] = cx; break; }
-            const char cy = comp_base(r[y]);
-            r[x] = cy;
-            r[y] = cx;
-            ++x;
-        }
-    }
+    const uint32_t tid = threadIdx.x;
+    if (chunk == 0 && tid == 0 && (len & 1)) r[half] = comp_base(r[half]);
+    const uint32_t s = chunk * seg;
+    if (s >= half) return;
+    const uint32_t e = s + seg < half ? s + seg : half, cnt = e - s;          // front [s, e), mirror [len-e, len-s)
+    char *ga = r + s, *gb = r + (len - e);
+    const uint32_t off_a = (uint32_t) ((uintptr_t) ga & 15), off_b = (uint32_t) ((uintptr_t) gb & 15);
+    ga -= off_a;
+    gb -= off_b;
+    for (uint32_t c = tid; 16 * c < off_a + cnt; c += 256)
+        *reinterpret_cast<uint4 *>(s_a + 16 * c) = *reinterpret_cast<const uint4 *>(ga + 16 * c);
+    for (uint32_t c = tid; 16 * c < off_b + cnt; c += 256)
+        *reinterpret_cast<uint4 *>(s_b + 16 * c) = *reinterpret_cast<const uint4 *>(gb + 16 * c);
+    __syncthreads();
+    revcomp_span(s_b, off_b, ga, off_a, cnt, tid);
+    revcomp_span(s_a, off_a, gb, off_b, cnt, tid);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -716,12 +753,14 @@ int lrm_launch_extend(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint64_t
                        idx->view, d_best, d_lens, n, d_meta, d_meta_r);
     lrm_time_end(ws, stream);
     {
-        uint32_t cpr = (max_len / 8 + 1 + 255) / 256;
+        const uint32_t half = max_len / 2 + 1;
+        const uint32_t cpr = (half + RC_SEG - 1) / RC_SEG;                                  // workgroups per read
+        const uint32_t seg = ((half + cpr - 1) / cpr + 15) & ~15u;                           // <= RC_SEG bases each
         uint64_t blocks = n * cpr;
         if (blocks > 0x7fffffffull) { lrm_set_error("revcomp grid too large: split the batch"); return -1; }
         lrm_time_begin(ws, LRM_K_REVCOMP, stream);
         hipLaunchKernelGGL(revcomp_kernel, dim3((uint32_t) blocks), dim3(256), 0, stream, d_reads, stride,
-                           d_lens, d_meta, d_meta_r, n, cpr);
+                           d_lens, d_meta, d_meta_r, n, cpr, seg);
         lrm_time_end(ws, stream);
     }
     LrmBsArgs bs = {};

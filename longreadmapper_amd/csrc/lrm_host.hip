@@ -59,9 +59,17 @@ struct DevSlot {
 };
 constexpr uint64_t STAGE_CHUNK = 32ull << 20;
 constexpr int N_SEED_STREAMS = 3;
-constexpr int N_EXT_STREAMS = 2;        // two groups in extension at once: a 25 k-read group fills a third of the SIMDs
+constexpr int N_EXT_STREAMS = 4;        // upper bound; run_slice uses n_ext_streams of them (LRM_HOST_EXT_STREAMS)
 constexpr int COPY_THREADS = 8;       // enough to outrun the link; a library must not fan out over every core of its host
-struct DevSet { DevSlot reads, lens, best, store, nops, score, meta, mr, dense, offs; };
+constexpr int N_DOWN = 2;             // download lanes available (run_slice uses one unless LRM_HOST_DOWN=2)
+struct DevSet { DevSlot reads, lens, best, store, nops, score, meta, mr; };
+// one download lane: its stream, its pair of pinned chunks, its dense result buffer + offset table on the device
+struct DownLane {
+    hipStream_t st = nullptr;
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    DevSlot dense, offs;
+};
 
 }  // namespace
 
@@ -70,9 +78,11 @@ struct LrmHostCtx {
     lrm_workspace *ws_seed[N_SEED_STREAMS] = {};   // seed-stage scratch, one per seed stream (sub-batch sized)
     lrm_workspace *ws_ext[N_EXT_STREAMS] = {};     // extension scratch (group sized), one per extension stream
     DevSet dev;                                    // device mirrors of the caller's arrays for one slice
-    void *pin_up[2] = {nullptr, nullptr}, *pin_dn[2] = {nullptr, nullptr};
-    hipStream_t up = nullptr, down = nullptr, seed[N_SEED_STREAMS] = {}, ext[N_EXT_STREAMS] = {};
-    hipEvent_t ev_pin_up[2] = {nullptr, nullptr}, ev_pin_dn[2] = {nullptr, nullptr};
+    void *pin_up[2] = {nullptr, nullptr};
+    DownLane dn[N_DOWN];
+    std::mutex err_mu;                   // the lanes poll the workspaces' sticky error words
+    hipStream_t up = nullptr, seed[N_SEED_STREAMS] = {}, ext[N_EXT_STREAMS] = {};
+    hipEvent_t ev_pin_up[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> ev_up, ev_seed, ev_ext;   // per sub-batch / per extension group, grown on demand
     bool pin_up_used[2] = {false, false};
     uint64_t up_seq = 0;
@@ -84,10 +94,12 @@ namespace {
 int ctx_init(LrmHostCtx &c) {
     if (c.ready) return 0;
     for (int b = 0; b < 2; ++b) {
-        if (hipHostMalloc(&c.pin_up[b], STAGE_CHUNK, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc(&c.pin_dn[b], STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) { lrm_set_error("pinned staging allocation failed"); return -1; }
-        if (hipEventCreateWithFlags(&c.ev_pin_up[b], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c.ev_pin_dn[b], hipEventDisableTiming) != hipSuccess) { lrm_set_error("event creation failed"); return -1; }
+        if (hipHostMalloc(&c.pin_up[b], STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) { lrm_set_error("pinned staging allocation failed"); return -1; }
+        if (hipEventCreateWithFlags(&c.ev_pin_up[b], hipEventDisableTiming) != hipSuccess) { lrm_set_error("event creation failed"); return -1; }
+        for (int l = 0; l < N_DOWN; ++l) {
+            if (hipHostMalloc(&c.dn[l].pin[b], STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) { lrm_set_error("pinned staging allocation failed"); return -1; }
+            if (hipEventCreateWithFlags(&c.dn[l].ev[b], hipEventDisableTiming) != hipSuccess) { lrm_set_error("event creation failed"); return -1; }
+        }
     }
     // Priorities: the result path first (pack kernels + downloads), then the extension of a finished group, then
     // the seed kernels of later sub-batches -- otherwise every group's extension finishes at the very end, behind
@@ -95,8 +107,9 @@ int ctx_init(LrmHostCtx &c) {
     int prio_lo = 0, prio_hi = 0;
     (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);          // numerically lower = higher priority
     const int p_seed = prio_lo, p_ext = prio_hi < prio_lo ? prio_lo - 1 : prio_lo, p_down = prio_hi;
-    if (hipStreamCreateWithPriority(&c.up, hipStreamNonBlocking, p_down) != hipSuccess ||
-        hipStreamCreateWithPriority(&c.down, hipStreamNonBlocking, p_down) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
+    if (hipStreamCreateWithPriority(&c.up, hipStreamNonBlocking, p_down) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
+    for (int l = 0; l < N_DOWN; ++l)
+        if (hipStreamCreateWithPriority(&c.dn[l].st, hipStreamNonBlocking, p_down) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
     for (int s = 0; s < N_EXT_STREAMS; ++s)
         if (hipStreamCreateWithPriority(&c.ext[s], hipStreamNonBlocking, p_ext) != hipSuccess) { lrm_set_error("stream creation failed"); return -1; }
     for (int s = 0; s < N_SEED_STREAMS; ++s)
@@ -192,26 +205,26 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const uint8_t *__restric
     }
 }
 
-// dense device buffer -> rows of a pitched host array: contiguous DMA through the pinned chunks, every chunk
+// dense device buffer -> rows of the caller's arrays: contiguous DMA through the lane's pinned chunks, every chunk
 // scattered into the caller's rows by COPY_THREADS threads while the next one flies.
-// off[i] (16-byte aligned, ascending) / len[i]: position and length of row i in the dense buffer; rows are
-// numbered from 0 and land at h_dst + i*pitch.
-int d2h_dense(LrmHostCtx &c, uint8_t *h_dst, uint64_t pitch, const uint8_t *d_dense, uint64_t total, const uint64_t *off,
-              const uint32_t *len, uint64_t rows) {
+// off[i] (16-byte aligned, ascending) / len[i]: position and length of entry i in the dense buffer; dst[i]: where
+// its bytes go.
+int d2h_dense(DownLane &L, const uint8_t *d_dense, uint64_t total, const uint64_t *off, const uint32_t *len,
+              uint8_t *const *dst, uint64_t rows) {
     if (total == 0) return 0;
     uint64_t k = 0, o = 0, prev_o = 0, prev_l = 0;
-    uint64_t row_lo = 0;                                              // first row that may still have bytes at or after prev_o
+    uint64_t row_lo = 0;                                              // first entry that may still have bytes at or after prev_o
     while (true) {
         const int b = (int) (k & 1);
         const uint64_t l = o < total ? (total - o < STAGE_CHUNK ? total - o : STAGE_CHUNK) : 0;
         if (l) {
-            HIPCHK(hipMemcpyAsync(c.pin_dn[b], d_dense + o, l, hipMemcpyDeviceToHost, c.down));
-            HIPCHK(hipEventRecord(c.ev_pin_dn[b], c.down));
+            HIPCHK(hipMemcpyAsync(L.pin[b], d_dense + o, l, hipMemcpyDeviceToHost, L.st));
+            HIPCHK(hipEventRecord(L.ev[b], L.st));
         }
         if (prev_l) {                                                 // scatter the previous chunk while this one flies
             const int pb = (int) ((k - 1) & 1);
-            HIPCHK(hipEventSynchronize(c.ev_pin_dn[pb]));
-            const uint8_t *chunk = (const uint8_t *) c.pin_dn[pb];
+            HIPCHK(hipEventSynchronize(L.ev[pb]));
+            const uint8_t *chunk = (const uint8_t *) L.pin[pb];
             const uint64_t c0 = prev_o, c1 = prev_o + prev_l;
             while (row_lo < rows && off[row_lo] + len[row_lo] <= c0) ++row_lo;
             uint64_t row_hi = row_lo;
@@ -219,7 +232,7 @@ int d2h_dense(LrmHostCtx &c, uint8_t *h_dst, uint64_t pitch, const uint8_t *d_de
 #pragma omp parallel for schedule(static) num_threads(COPY_THREADS)
             for (uint64_t r = row_lo; r < row_hi; ++r) {
                 const uint64_t a = off[r] > c0 ? off[r] : c0, e = off[r] + len[r] < c1 ? off[r] + len[r] : c1;
-                if (e > a) memcpy(h_dst + r * pitch + (a - off[r]), chunk + (a - c0), e - a);
+                if (e > a) memcpy(dst[r] + (a - off[r]), chunk + (a - c0), e - a);
             }
         }
         if (l == 0) break;
@@ -304,6 +317,7 @@ struct Pipe {
 struct Range { uint64_t off, m; };
 
 int take_errors(LrmHostCtx &c) {
+    std::lock_guard<std::mutex> g(c.err_mu);
     int rc = 0;
     for (int s = 0; s < N_SEED_STREAMS; ++s) if (lrm_ws_take_error(c.ws_seed[s])) rc = -2;
     for (int s = 0; s < N_EXT_STREAMS; ++s) if (lrm_ws_take_error(c.ws_ext[s])) rc = -2;
@@ -311,21 +325,21 @@ int take_errors(LrmHostCtx &c) {
 }
 
 // download of one unit [off, off + m) of the slice (runs on the download thread once `done` has fired)
-int collect(LrmHostCtx &c, const MapJob &j, const Range &u, hipEvent_t done, uint64_t dstride, const HostClock &clk) {
+int collect(LrmHostCtx &c, DownLane &L, const MapJob &j, const Range &u, hipEvent_t done, uint64_t dstride, const HostClock &clk) {
     DevSet &d = c.dev;
     const double t_in = clk.ms();
     HIPCHK(hipEventSynchronize(done));
     const double t_done = clk.ms();
     if (take_errors(c)) return -2;                                   // raised by this or an earlier unit: never lost
     const uint64_t m = u.m, o = u.off;
-    if (j.mode & DO_SEED) HIPCHK(hipMemcpyAsync(j.best_out + o, (const lrm_entry *) d.best.p + o, m * sizeof(lrm_entry), hipMemcpyDeviceToHost, c.down));
-    if (!(j.mode & DO_EXTEND)) { HIPCHK(hipStreamSynchronize(c.down)); return 0; }
+    if (j.mode & DO_SEED) HIPCHK(hipMemcpyAsync(j.best_out + o, (const lrm_entry *) d.best.p + o, m * sizeof(lrm_entry), hipMemcpyDeviceToHost, L.st));
+    if (!(j.mode & DO_EXTEND)) { HIPCHK(hipStreamSynchronize(L.st)); return 0; }
     std::vector<int32_t> nops(m);
-    HIPCHK(hipMemcpyAsync(nops.data(), (const int32_t *) d.nops.p + o, m * 4, hipMemcpyDeviceToHost, c.down));
-    HIPCHK(hipMemcpyAsync(j.score + o, (const int32_t *) d.score.p + o, m * 4, hipMemcpyDeviceToHost, c.down));
-    HIPCHK(hipMemcpyAsync(j.meta + o, (const lrm_seq_meta *) d.meta.p + o, m * sizeof(lrm_seq_meta), hipMemcpyDeviceToHost, c.down));
-    HIPCHK(hipMemcpyAsync(j.meta_r + o, (const int32_t *) d.mr.p + o, m * 4, hipMemcpyDeviceToHost, c.down));
-    HIPCHK(hipStreamSynchronize(c.down));
+    HIPCHK(hipMemcpyAsync(nops.data(), (const int32_t *) d.nops.p + o, m * 4, hipMemcpyDeviceToHost, L.st));
+    HIPCHK(hipMemcpyAsync(j.score + o, (const int32_t *) d.score.p + o, m * 4, hipMemcpyDeviceToHost, L.st));
+    HIPCHK(hipMemcpyAsync(j.meta + o, (const lrm_seq_meta *) d.meta.p + o, m * sizeof(lrm_seq_meta), hipMemcpyDeviceToHost, L.st));
+    HIPCHK(hipMemcpyAsync(j.meta_r + o, (const int32_t *) d.mr.p + o, m * 4, hipMemcpyDeviceToHost, L.st));
+    HIPCHK(hipStreamSynchronize(L.st));
     // dense layout: the used part of every CIGAR row, then the reads that were reverse-complemented in place
     // (alnmain.c:437; the other rows of reads_buf did not change)
     std::vector<uint64_t> off(2 * m);
@@ -337,7 +351,6 @@ int collect(LrmHostCtx &c, const MapJob &j, const Range &u, hipEvent_t done, uin
         off[i] = total;
         total += ((uint64_t) len[i] + 15) & ~15ull;
     }
-    const uint64_t total_ops = total;
     for (uint64_t i = 0; i < m; ++i) {
         const bool rev = j.meta_r[o + i] != 0 && j.meta[o + i].strand == 1;
         len[m + i] = rev ? j.lens[o + i] : 0u;
@@ -350,34 +363,35 @@ int collect(LrmHostCtx &c, const MapJob &j, const Range &u, hipEvent_t done, uin
                         is_pinned(j.store_mem + o * j.store_stride, &store_alias) && store_alias &&
                         is_pinned(j.reads + o * j.stride, &reads_alias) && reads_alias;
     if (total) {
-        if (d.offs.ensure(2 * m * 12)) { lrm_set_error("device allocation failed"); return -1; }
-        uint64_t *d_off = (uint64_t *) d.offs.p;
-        uint32_t *d_len = (uint32_t *) ((uint8_t *) d.offs.p + 2 * m * 8);
-        HIPCHK(hipMemcpyAsync(d_len, len.data(), 2 * m * 4, hipMemcpyHostToDevice, c.down));
+        if (L.offs.ensure(2 * m * 12)) { lrm_set_error("device allocation failed"); return -1; }
+        uint64_t *d_off = (uint64_t *) L.offs.p;
+        uint32_t *d_len = (uint32_t *) ((uint8_t *) L.offs.p + 2 * m * 8);
+        HIPCHK(hipMemcpyAsync(d_len, len.data(), 2 * m * 4, hipMemcpyHostToDevice, L.st));
         const uint32_t gy_ops = (uint32_t) ((j.store_stride + 4095) / 4096), gy_rd = (uint32_t) ((j.stride + 4095) / 4096);
         if (direct) {
             // LRM_HOST_DIRECT=1 with pinned caller buffers: the device writes the rows straight into them as posted
             // writes.  Measured slower than the dense DMA + host scatter on this platform (23 GB/s against 57), so off
             // by default.
-            hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t) m, gy_ops ? gy_ops : 1), dim3(256), 0, c.down, d_store, dstride,
+            hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t) m, gy_ops ? gy_ops : 1), dim3(256), 0, L.st, d_store, dstride,
                                (uint8_t *) store_alias, j.store_stride, d_len, m);
-            hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t) m, gy_rd ? gy_rd : 1), dim3(256), 0, c.down, d_reads, j.stride,
+            hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t) m, gy_rd ? gy_rd : 1), dim3(256), 0, L.st, d_reads, j.stride,
                                (uint8_t *) reads_alias, j.stride, d_len + m, m);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(c.down));
+            HIPCHK(hipStreamSynchronize(L.st));
         } else {
-            if (d.dense.ensure(total)) { lrm_set_error("device allocation failed"); return -1; }
-            HIPCHK(hipMemcpyAsync(d_off, off.data(), 2 * m * 8, hipMemcpyHostToDevice, c.down));
-            hipLaunchKernelGGL(pack_rows_kernel, dim3((uint32_t) m, gy_ops ? gy_ops : 1), dim3(256), 0, c.down, d_store, dstride,
-                               d_len, d_off, (uint8_t *) d.dense.p, m);
-            hipLaunchKernelGGL(pack_rows_kernel, dim3((uint32_t) m, gy_rd ? gy_rd : 1), dim3(256), 0, c.down, d_reads, j.stride,
-                               d_len + m, d_off + m, (uint8_t *) d.dense.p, m);
+            if (L.dense.ensure(total)) { lrm_set_error("device allocation failed"); return -1; }
+            HIPCHK(hipMemcpyAsync(d_off, off.data(), 2 * m * 8, hipMemcpyHostToDevice, L.st));
+            hipLaunchKernelGGL(pack_rows_kernel, dim3((uint32_t) m, gy_ops ? gy_ops : 1), dim3(256), 0, L.st, d_store, dstride,
+                               d_len, d_off, (uint8_t *) L.dense.p, m);
+            hipLaunchKernelGGL(pack_rows_kernel, dim3((uint32_t) m, gy_rd ? gy_rd : 1), dim3(256), 0, L.st, d_reads, j.stride,
+                               d_len + m, d_off + m, (uint8_t *) L.dense.p, m);
             HIPCHK(hipGetLastError());
-            if (d2h_dense(c, j.store_mem + o * j.store_stride, j.store_stride, (const uint8_t *) d.dense.p, total_ops, off.data(),
-                          len.data(), m)) return -1;
-            for (uint64_t i = 0; i < m; ++i) off[m + i] -= total_ops;        // the reads part: offsets relative to its own start
-            if (d2h_dense(c, (uint8_t *) j.reads + o * j.stride, j.stride, (const uint8_t *) d.dense.p + total_ops, total - total_ops,
-                          off.data() + m, len.data() + m, m)) return -1;
+            std::vector<uint8_t *> dst(2 * m);
+            for (uint64_t i = 0; i < m; ++i) {
+                dst[i] = j.store_mem + (o + i) * j.store_stride;
+                dst[m + i] = (uint8_t *) j.reads + (o + i) * j.stride;
+            }
+            if (d2h_dense(L, (const uint8_t *) L.dense.p, total, off.data(), len.data(), dst.data(), 2 * m)) return -1;
         }
     }
     for (uint64_t i = 0; i < m; ++i) {                               // alnmain.c:322-325, mutils.c:99-104
@@ -411,6 +425,10 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
         units.push_back({subs[k0].off, subs[ends[g] - 1].off + subs[ends[g] - 1].m - subs[k0].off});
         for (size_t k = k0; k < ends[g]; ++k) unit_of[k] = g;
     }
+    // groups in extension at once.  The lane-per-read kernel has a fixed latency per group (a lane walks its read's
+    // tiles one after the other: ~7.6 ms for 10 kbp), and a 17 k-read group fills a quarter of the SIMDs.
+    int n_ext_streams = 2;
+    if (const char *e = getenv("LRM_HOST_EXT_STREAMS")) { const int v = atoi(e); if (v >= 1 && v <= N_EXT_STREAMS) n_ext_streams = v; }   // tuning knob
     uint64_t unit_max = 0;
     for (auto &u : units) unit_max = u.m > unit_max ? u.m : unit_max;
     if (n > 0x7fffffffull) { lrm_set_error("batch too large"); return -1; }
@@ -418,7 +436,7 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
         for (int s = 0; s < N_SEED_STREAMS && (size_t) s < subs.size(); ++s)
             if (get_ws(c.ws_seed[s], idx, sub, max_len, j.p.seed_len, j.p.thres, LRM_WS_SEED)) return -1;
     if (j.mode & DO_EXTEND)
-        for (int s = 0; s < N_EXT_STREAMS && (size_t) s < units.size(); ++s)
+        for (int s = 0; s < n_ext_streams && (size_t) s < units.size(); ++s)
             if (get_ws(c.ws_ext[s], idx, unit_max, max_len, 20, 300, LRM_WS_EXTEND)) return -1;
     if (ensure_events(c.ev_up, subs.size()) || ensure_events(c.ev_seed, subs.size()) || ensure_events(c.ev_ext, units.size())) return -1;
     DevSet &d = c.dev;
@@ -427,15 +445,26 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
     //  never reallocates -- a hipFree would drain the whole device -- while other units are in flight)
     if ((j.mode & DO_EXTEND) && (d.store.ensure(n * dstride) || d.nops.ensure(n * 4) || d.score.ensure(n * 4) ||
                                   d.meta.ensure(n * sizeof(lrm_seq_meta)) || d.mr.ensure(n * 4) ||
-                                  d.dense.ensure(unit_max * (dstride + j.stride + 32)) || d.offs.ensure(unit_max * 2 * 12))) { lrm_set_error("device allocation failed"); return -1; }
+                                  false)) { lrm_set_error("device allocation failed"); return -1; }
+    int n_down = 1;
+    if (const char *e = getenv("LRM_HOST_DOWN")) { const int v = atoi(e); if (v >= 1 && v <= N_DOWN && (size_t) v <= units.size()) n_down = v; }   // tuning knob
+    if (j.mode & DO_EXTEND)
+        for (int l = 0; l < n_down; ++l)
+            if (c.dn[l].dense.ensure(unit_max * (dstride + j.stride + 32)) || c.dn[l].offs.ensure(unit_max * 2 * 12)) { lrm_set_error("device allocation failed"); return -1; }
 
     Pipe pipe;
     HostClock clk;
     const int device = idx->device;
     const bool seed_only = !(j.mode & DO_EXTEND);
-    std::thread downloader([&]() {
+    // Download lanes: unit g is collected by lane g % n_down.  One lane by default.  A second lane was meant to hide
+    // the fixed costs of a unit (small copies, offset table, pack kernels, the first chunk's flight and the last
+    // chunk's scatter: ~1.7 of 6.1 ms per 256 MB unit) behind the other lane's DMA; measured on a 16-core host it
+    // is slower (pinned 71 vs 70 ms per 100 k x 10 kbp batch, pageable 99 vs 73: two scatter teams plus the upload
+    // staging oversubscribe the cores, and the two DMA queues share one link), so LRM_HOST_DOWN=2 is opt-in.
+    // Likewise three or four extension streams instead of two (LRM_HOST_EXT_STREAMS): 72-74 ms against 70-71.
+    auto lane = [&](int ln) {
         if (hipSetDevice(device) != hipSuccess) { lrm_set_error("hipSetDevice failed on the download thread"); pipe.fail(-1); return; }
-        for (uint64_t g = 0; g < units.size(); ++g) {
+        for (uint64_t g = (uint64_t) ln; g < units.size(); g += (uint64_t) n_down) {
             {
                 std::unique_lock<std::mutex> lk(pipe.m);
                 pipe.cv.wait(lk, [&] { return pipe.issued > g || pipe.stop || pipe.rc; });
@@ -444,11 +473,13 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
             // seed-only: a unit is done when the seeds of its last sub-batch are (sub-batches of a seed stream are ordered)
             hipEvent_t done = seed_only ? c.ev_seed[ends[g] - 1] : c.ev_ext[g];
             int rc;
-            try { rc = collect(c, j, units[g], done, dstride, clk); }
+            try { rc = collect(c, c.dn[ln], j, units[g], done, dstride, clk); }
             catch (const std::exception &e) { lrm_set_error("download thread: %s", e.what()); rc = -1; }
             if (rc) { pipe.fail(rc); return; }
         }
-    });
+    };
+    std::vector<std::thread> downloaders;
+    for (int l = 0; l < n_down; ++l) downloaders.emplace_back(lane, l);
 
     int rc = 0;
     int n_seed_streams = 2;
@@ -472,7 +503,7 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
             const uint64_t g = unit_of[k];
             const bool closes = k + 1 == ends[g];
             if (closes && (j.mode & DO_EXTEND)) {                                  // the group's extension, behind its seeds / uploads
-                const int xs = (int) (g % N_EXT_STREAMS);
+                const int xs = (int) (g % (uint64_t) n_ext_streams);
                 for (uint64_t x = g ? ends[g - 1] : 0; x <= k; ++x) HIPCHK(hipStreamWaitEvent(c.ext[xs], (j.mode & DO_SEED) ? c.ev_seed[x] : c.ev_up[x], 0));
                 const Range &u = units[g];
                 if (lrm_launch_extend(idx, c.ws_ext[xs], (char *) d.reads.p + u.off * j.stride, j.stride, (const uint32_t *) d.lens.p + u.off, u.m,
@@ -494,12 +525,13 @@ int run_slice(lrm_index *idx, LrmHostCtx &c, const MapJob &j, uint32_t max_len) 
     }
     { std::lock_guard<std::mutex> lk(pipe.m); pipe.stop = true; }
     pipe.cv.notify_all();
-    downloader.join();
+    for (auto &t : downloaders) t.join();
     if (clk.on) fprintf(stderr, "[lrm host] slice of %llu reads, %zu seed sub-batches, %zu units: %.1f ms\n", (unsigned long long) n, subs.size(), units.size(), clk.ms());
     if (pipe.rc) {
         for (int s = 0; s < N_SEED_STREAMS; ++s) (void) hipStreamSynchronize(c.seed[s]);
         for (int s = 0; s < N_EXT_STREAMS; ++s) (void) hipStreamSynchronize(c.ext[s]);
-        (void) hipStreamSynchronize(c.up); (void) hipStreamSynchronize(c.down);
+        (void) hipStreamSynchronize(c.up);
+        for (int l = 0; l < N_DOWN; ++l) (void) hipStreamSynchronize(c.dn[l].st);
         (void) take_errors(c);                                        // reported now: do not fail the next call
         lrm_set_error("%s", pipe.err);
         return pipe.rc;
@@ -594,12 +626,15 @@ void lrm_host_ctx_free(lrm_index *idx) {
     if (c->ready) {
         for (int s = 0; s < N_SEED_STREAMS; ++s) (void) hipStreamSynchronize(c->seed[s]);
         for (int s = 0; s < N_EXT_STREAMS; ++s) (void) hipStreamSynchronize(c->ext[s]);
-        (void) hipStreamSynchronize(c->up); (void) hipStreamSynchronize(c->down);
+        (void) hipStreamSynchronize(c->up);
+        for (int l = 0; l < N_DOWN; ++l) (void) hipStreamSynchronize(c->dn[l].st);
         for (int b = 0; b < 2; ++b) {
-            (void) hipHostFree(c->pin_up[b]); (void) hipHostFree(c->pin_dn[b]);
-            (void) hipEventDestroy(c->ev_pin_up[b]); (void) hipEventDestroy(c->ev_pin_dn[b]);
+            (void) hipHostFree(c->pin_up[b]);
+            (void) hipEventDestroy(c->ev_pin_up[b]);
+            for (int l = 0; l < N_DOWN; ++l) { (void) hipHostFree(c->dn[l].pin[b]); (void) hipEventDestroy(c->dn[l].ev[b]); }
         }
-        (void) hipStreamDestroy(c->up); (void) hipStreamDestroy(c->down);
+        (void) hipStreamDestroy(c->up);
+        for (int l = 0; l < N_DOWN; ++l) (void) hipStreamDestroy(c->dn[l].st);
         for (int s = 0; s < N_EXT_STREAMS; ++s) (void) hipStreamDestroy(c->ext[s]);
         for (int s = 0; s < N_SEED_STREAMS; ++s) (void) hipStreamDestroy(c->seed[s]);
     }
@@ -608,7 +643,8 @@ void lrm_host_ctx_free(lrm_index *idx) {
     for (int s = 0; s < N_EXT_STREAMS; ++s) if (c->ws_ext[s]) lrm_workspace_free(c->ws_ext[s]);
     DevSet &d = c->dev;
     d.reads.release(); d.lens.release(); d.best.release(); d.store.release();
-    d.nops.release(); d.score.release(); d.meta.release(); d.mr.release(); d.dense.release(); d.offs.release();
+    d.nops.release(); d.score.release(); d.meta.release(); d.mr.release();
+    for (int l = 0; l < N_DOWN; ++l) { c->dn[l].dense.release(); c->dn[l].offs.release(); }
     delete c;
 }
 

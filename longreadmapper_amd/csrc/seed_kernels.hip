@@ -229,7 +229,7 @@ __device__ __forceinline__ uint64_t read_window(const uint64_t *__restrict__ wor
 }
 
 // ----------------------------------------------------------------------------------------
-// K1 seed_search: one lane per seed, SS_ITEMS seeds per workgroup (4 per thread).  Work items of a read are
+// K1 seed_search: one lane per seed, SS_ITEMS seeds per workgroup (8 per thread).  Work items of a read are
 // (q, iter) with iter fastest, so the 64 lanes of a wavefront hold 64 CONSECUTIVE read positions.
 // Output: the SURVIVORS only (0 < rr < thres, ~25 % of the seeds of a noisy read), compact per (read, phase):
 //   rec [id][0 .. cnt[id])   k | rr << 40         recq[id][..]  seed ordinal q        (id = read*P + phase)
@@ -240,7 +240,9 @@ __device__ __forceinline__ uint64_t read_window(const uint64_t *__restrict__ wor
 // and every vote tier re-read all of it.)  The order of a list does not matter: the first-seen order key of a hit,
 // (q << tbits) | t, is a property of the hit.
 // ----------------------------------------------------------------------------------------
-#define SS_ITEMS 1024
+#ifndef SS_ITEMS
+#define SS_ITEMS 2048                  // seeds per workgroup (measured, tools/build_probe.py: 512 26.2 ms, 1024 25.5, 2048 25.0)
+#endif
 __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const uint64_t *__restrict__ reads2,
                                                           uint64_t words_per_read,
                                                           const uint32_t *__restrict__ lens,
@@ -616,7 +618,8 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
     // Items that need several passes (ultra-long reads: ~3500 hits, five passes): the first pass writes every hit's
     // {key, order key} to this workgroup's slice of a global scratch, and the later passes stream them back
     // (12 coalesced bytes per hit) instead of searching, gathering and subtracting again.
-    const bool cache = passes > 1 && H <= kc_cap;
+    // (from three passes on: with two, writing and re-reading 12 B per hit costs as much traffic as it saves)
+    const bool cache = passes > 2 && H <= kc_cap;
     {
         const uint32_t per_pass = passes > 1 ? limit : H;
         const uint32_t eff = per_pass * 100u / load + 64;

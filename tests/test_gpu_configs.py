@@ -129,3 +129,28 @@ def test_largest_tile_and_band(ref3):
     seqs, hi, di, oi = ref3
     r = synth.reads(seqs, 8, 3_000, synth.ONT, seed=19)
     _compare(di, oi, r["reads"], r["lens"], (512, 0, 1024))
+
+
+def test_revcomp_in_place_ragged_rows(ref3):
+    """`_rev_comp_in_place` (alnmain.c:27-60) on rows of every alignment: lengths 1..70, around the kernel's
+    4096-base span boundaries, odd and even, with lower-case and non-ACGT bytes (-> 'N'), every read placed on the
+    reverse strand by its locus; forward-strand rows in between must stay untouched."""
+    seqs, hi, di, oi = ref3
+    lens = list(range(1, 71)) + [4095, 4096, 4097, 8191, 8192, 8193, 8223, 8224, 8225, 12289, 16384, 16399, 20001]
+    n, mx = len(lens), max(lens)
+    rng = np.random.default_rng(5)
+    reads = np.frombuffer(b"ACGTacgtNRY-", dtype=np.uint8)[rng.integers(0, 12, size=(n, mx + 1))].copy()
+    lens = np.array(lens, dtype=np.uint32)
+    for i in range(n):
+        reads[i, lens[i]:] = 0
+    best = np.zeros(n, dtype=mapper.ENTRY_DT)
+    L0 = len(seqs[0])
+    best["key"] = np.where(np.arange(n) % 3 == 2, 1000 + 37 * np.arange(n), L0 + 5000 + 41 * np.arange(n))   # seq 0: fwd / revcomp half
+    rc, rg = reads.copy(), reads.copy()
+    want = oi.extend_batch(rc, lens, best, (64, 16, 32), nthreads=8)
+    got = mapper.extend_batch(di, rg, lens, best, (64, 16, 32))
+    assert np.array_equal(got["meta_r"], want["meta_r"]) and (want["meta_r"] == 1).all()
+    assert (got["meta"]["strand"] == (np.arange(n) % 3 != 2)).all()
+    assert np.array_equal(rc, rg)
+    assert not np.array_equal(rg, reads)
+    assert np.array_equal(got["score"], want["score"]) and np.array_equal(got["n_ops"], want["n_ops"])
