@@ -65,9 +65,15 @@ __device__ __forceinline__ void bs_pack_group(const uint8_t *src, uint64_t len, 
 }
 
 // reads: word w of read r at out + r*wpr + BS_PADW + w; padding words are zeroed.
-// One wavefront per BS_PACK_G groups of 64 bases: all its byte loads are issued before the first ballot
-// (one memory latency per 1 KiB of read instead of one per 64 bytes).
+// One wavefront per BS_PACK_G groups of 64 bases (1 KiB of a read): every lane takes 16 bases with two ALIGNED
+// 16-byte loads (rows start at any byte: stride = max_read_len + 1) and v_alignbyte, turns them into 16 low and 16
+// high plane bits with multiplies (no ballots), and pairs of lanes assemble the 64-bit words.  (The first version
+// loaded one byte per lane and built the planes with 48 ballots per KiB: 0.72 ms per Gbp [r2].)
 #define BS_PACK_G 16
+__device__ __forceinline__ uint32_t bs_bytes_equal(uint32_t x, uint32_t c4) {    // 0x80 in every byte of x equal to c4's
+    const uint32_t z = x ^ c4;
+    return ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z | 0x7F7F7F7Fu);
+}
 __global__ __launch_bounds__(256) void bs_pack_reads_kernel(const char *__restrict__ reads, uint64_t stride,
                                                             const uint32_t *__restrict__ lens,
                                                             uint64_t *__restrict__ out, uint64_t wpr,
@@ -78,35 +84,55 @@ __global__ __launch_bounds__(256) void bs_pack_reads_kernel(const char *__restri
     const uint64_t r = wave_id / waves_per_read;
     const uint32_t part = (uint32_t) (wave_id % waves_per_read);
     if (r >= n) return;
-    const uint64_t len = lens[r];
+    const uint32_t len = lens[r];
     uint64_t *o = out + r * wpr;
     if (part == 0) {
         for (uint64_t w = lane; w < BS_PADW; w += 64) o[w] = 0;
         for (uint64_t w = BS_PADW + 2ull * groups_per_read + lane; w < wpr; w += 64) o[w] = 0;
     }
-    const uint8_t *src = reinterpret_cast<const uint8_t *>(reads) + r * stride;
+    const uint8_t *row = reinterpret_cast<const uint8_t *>(reads) + r * stride;
     const uint32_t g0 = part * BS_PACK_G;
-    uint32_t c[BS_PACK_G];
+    const uint32_t p0 = g0 * 64 + 16 * (uint32_t) lane;               // this lane's 16 bases: [p0, p0 + 16)
+    uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint8_t *src = row + p0;
+    const uint32_t sh = (uint32_t) ((uintptr_t) src & 15u);           // the same in every lane of the wavefront
+    if (p0 < len) {                                                   // both loads touch a 16-byte line that holds a base of the read
+        const uint4 q0 = *reinterpret_cast<const uint4 *>(src - sh);
+        d[0] = q0.x; d[1] = q0.y; d[2] = q0.z; d[3] = q0.w;
+        if (sh && p0 + (16 - sh) < len) {
+            const uint4 q1 = *reinterpret_cast<const uint4 *>(src - sh + 16);
+            d[4] = q1.x; d[5] = q1.y; d[6] = q1.z; d[7] = q1.w;
+        }
+    }
+    const uint32_t ws = sh >> 2, bs = sh & 3;                          // dword and byte part of the shift (wave-uniform)
+    uint32_t lo = 0, hi = 0, bad = 0;
 #pragma unroll
-    for (int e = 0; e < BS_PACK_G; ++e) {
-        const uint64_t p = (uint64_t) (g0 + e) * 64 + (uint64_t) lane;
-        c[e] = p < len ? src[p] : (uint32_t) 'A';                     // bases past the end pack as A, unflagged
+    for (int k = 0; k < 4; ++k) {
+        uint32_t a_ = d[k], b_ = d[k + 1];
+        if (ws == 1) { a_ = d[k + 1]; b_ = d[k + 2]; }
+        else if (ws == 2) { a_ = d[k + 2]; b_ = d[k + 3]; }
+        else if (ws == 3) { a_ = d[k + 3]; b_ = d[k + 4]; }
+        uint32_t x = __builtin_amdgcn_alignbyte(b_, a_, bs);           // bases p0 + 4k .. p0 + 4k + 3
+        const uint32_t pk = p0 + 4 * (uint32_t) k;
+        const uint32_t nv = len > pk ? (len - pk < 4 ? len - pk : 4) : 0;          // bases of this dword inside the read
+        const uint32_t keep = nv >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nv)) - 1u);
+        x = (x & keep) | (0x41414141u & ~keep);                        // bases past the end pack as A, unflagged
+        const uint32_t code = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+        lo |= ((((code & 0x01010101u) * 0x01020408u) >> 24) & 0xFu) << (4 * k);
+        hi |= (((((code >> 1) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu) << (4 * k);
+        const uint32_t ok = bs_bytes_equal(x, 0x41414141u) | bs_bytes_equal(x, 0x43434343u) |
+                            bs_bytes_equal(x, 0x47474747u) | bs_bytes_equal(x, 0x54545454u);
+        bad |= ~ok & 0x80808080u;
     }
-    uint64_t lo = 0, hi = 0, bad = 0;                                 // lane e keeps group e's planes
-#pragma unroll
-    for (int e = 0; e < BS_PACK_G; ++e) {
-        const uint32_t code = ((c[e] >> 1) ^ (c[e] >> 2)) & 3u;
-        const uint64_t l_ = __ballot(code & 1u), h_ = __ballot(code >> 1);
-        const uint64_t b_ = __ballot(!(c[e] == 'A' || c[e] == 'C' || c[e] == 'G' || c[e] == 'T'));
-        if (lane == e) { lo = l_; hi = h_; }
-        bad |= b_;
+    const uint32_t mine = lo | (hi << 16);
+    const uint32_t other = (uint32_t) __shfl_xor((int) mine, 1);
+    if (!(lane & 1) && g0 + (uint32_t) (lane >> 2) < groups_per_read) {
+        // word (lane >> 1) of the wavefront's 32: low planes of 32 bases in the low half, high planes in the high half
+        const uint64_t w = (uint64_t) (mine & 0xFFFFu) | ((uint64_t) (other & 0xFFFFu) << 16) |
+                           ((uint64_t) (mine >> 16) << 32) | ((uint64_t) (other >> 16) << 48);
+        o[BS_PADW + 2ull * g0 + (uint32_t) (lane >> 1)] = w;
     }
-    if (lane < BS_PACK_G && g0 + (uint32_t) lane < groups_per_read) {
-        uint64_t *w = o + BS_PADW + 2ull * (g0 + (uint32_t) lane);
-        w[0] = (lo & 0xffffffffull) | (hi << 32);
-        w[1] = (lo >> 32) | (hi & 0xffffffff00000000ull);
-    }
-    if (bad && lane == 0) atomicOr(flags + r, 1u);
+    if (__ballot(bad != 0) && lane == 0) atomicOr(flags + r, 1u);
 }
 
 // reference text: one wavefront per 64 KiB
