@@ -171,7 +171,7 @@ struct BlobPacker {
         return code;
     }
 
-    // occ blocks [b0, b0 + nb): one {prefix count, occurrence mask} pair per symbol and 64 bwt rows;
+    // occ blocks [b0, b0 + nb): one {C[sym] + prefix count, occurrence mask} pair per symbol and 64 bwt rows;
     // cross-checked against the reference's sampled O table (fmidx.c:128-150)
     int fill_occ(uint64_t b0, uint64_t nb, LrmOccBlock *dst) const {
         const uint64_t ratio = (uint64_t) fmi->o_ratio;
@@ -189,7 +189,7 @@ struct BlobPacker {
             for (uint64_t i = sg * SEG; i < blo * LRM_OCC_ROWS && i < L; ++i) { const int c = code_of(fmi->bwt[i]); if (c >= 0) run[c]++; }
             for (uint64_t b = blo; b < bhi; ++b) {
                 LrmOccBlock blk;
-                for (int x = 0; x < 4; ++x) { blk.sym[x].cnt = run[x]; blk.sym[x].mask = 0; }
+                for (int x = 0; x < 4; ++x) { blk.sym[x].cnt = h.c4[x] + run[x]; blk.sym[x].mask = 0; }
                 const uint64_t r0 = b * LRM_OCC_ROWS, r1 = r0 + LRM_OCC_ROWS < L ? r0 + LRM_OCC_ROWS : L;
                 for (uint64_t i = r0; i < r1; ++i) {
                     if (fmi->o && ratio > 0 && i % ratio == 0) {

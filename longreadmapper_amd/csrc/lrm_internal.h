@@ -28,13 +28,13 @@
 #include <stdint.h>
 #include "../../include/lrm_accel.h"
 
-#define LRM_BLOB_MAGIC 0x4c524d424c4f4231ull   // "LRMBLOB1"
+#define LRM_BLOB_MAGIC 0x4c524d424c4f4232ull   // "LRMBLOB2" (2: C[] folded into the occ prefixes)
 #define LRM_OCC_ROWS 64
 
-// One rank query = ONE 16-byte gather + one 64-bit popcount: per 64 BWT rows and per symbol a
-// {rank prefix, occurrence bitmask} pair; the four symbols of a block share a 64-byte line.
+// One LF step = ONE 16-byte gather + one 64-bit popcount: per 64 BWT rows and per symbol a
+// {C[sym] + rank prefix, occurrence bitmask} pair; the four symbols of a block share a 64-byte line.
 struct LrmOccEntry {
-    uint64_t cnt;       // # of this symbol in bwt[0 .. 64*blk)
+    uint64_t cnt;       // C[sym] + # of this symbol in bwt[0 .. 64*blk): an LF step is cnt + popcount(mask bits 0..r)
     uint64_t mask;      // bit r set <=> bwt[64*blk + r] is this symbol ('$' sets no bit)
 };
 struct LrmOccBlock { LrmOccEntry sym[4]; };

@@ -53,34 +53,25 @@ __global__ __launch_bounds__(256) void pack2bit_kernel(const char *__restrict__ 
 }
 
 // ----------------------------------------------------------------------------------------
-// FM rank: rank(c, loc) = # of c in bwt[0..loc] == _occ_access (fmidx.c:277-293).
-// One 16-byte gather {prefix, mask} and one popcount.  The kernel is bound by the number of
-// per-lane memory requests, not by bytes or ALU, so the layout is built to make a rank ONE request.
+// FM LF-mapping: lf(c, loc) = C[c] + rank(c, loc), rank = # of c in bwt[0..loc] == _occ_access (fmidx.c:277-293)
+// and C[] as fmi_aln adds it (fmidx.c:305-311).  One 16-byte gather {C[c] + prefix, mask}, one shift and one
+// popcount.  The kernel is bound by the number of per-lane memory requests, then by its 64-bit index arithmetic,
+// so the layout is built to make an LF step ONE request and the packer folds C[c] into the stored prefix (the
+// first version selected C[c] from four scalar pairs in every step: 14 of its ~63 vector instructions).
 // ----------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t occ_rank(const LrmIndexView &ix, uint32_t c, uint64_t loc) {
-    const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(&ix.occ[loc >> 6].sym[c]);
-    const uint32_t r = (uint32_t) loc & 63u;
-    return e.x + (uint64_t) __popcll(e.y & (~0ull >> (63u - r)));
+__device__ __forceinline__ uint64_t occ_lf_of(const ulonglong2 e, uint64_t loc) {
+    return e.x + (uint64_t) __popcll(e.y << (63u - ((uint32_t) loc & 63u)));          // bits 0 .. loc % 64 of the mask
 }
 
-// the two ranks of one backward step; after the table lookup most intervals are a handful of rows,
+// the two LF values of one backward step; after the table lookup most intervals are a handful of rows,
 // so k-1 and l usually fall into the same 64-row block and ONE 16-byte request serves both
-__device__ __forceinline__ void occ_rank2(const LrmIndexView &ix, uint32_t c, uint64_t loc_a, uint64_t loc_b,
-                                          uint64_t &ra, uint64_t &rb) {
+__device__ __forceinline__ void occ_lf2(const LrmIndexView &ix, uint32_t c, uint64_t loc_a, uint64_t loc_b,
+                                        uint64_t &ra, uint64_t &rb) {
     const ulonglong2 eb = *reinterpret_cast<const ulonglong2 *>(&ix.occ[loc_b >> 6].sym[c]);
     ulonglong2 ea = eb;
     if ((loc_a >> 6) != (loc_b >> 6)) ea = *reinterpret_cast<const ulonglong2 *>(&ix.occ[loc_a >> 6].sym[c]);
-    const uint32_t qa = (uint32_t) loc_a & 63u, qb = (uint32_t) loc_b & 63u;
-    ra = ea.x + (uint64_t) __popcll(ea.y & (~0ull >> (63u - qa)));       // bits 0 .. qa
-    rb = eb.x + (uint64_t) __popcll(eb.y & (~0ull >> (63u - qb)));
-}
-
-// C[c] (fmidx.c:101-125) from the by-value view: a select over four scalar registers.  Indexing the array with the
-// lane's symbol made the compiler fetch it from the kernel-argument segment with a vector load -- one more memory
-// request in every backward step of a kernel that is bound by the number of requests.
-__device__ __forceinline__ uint64_t c4_of(const LrmIndexView &ix, uint32_t c) {
-    const uint64_t lo = (c & 1u) ? ix.c4[1] : ix.c4[0], hi = (c & 1u) ? ix.c4[3] : ix.c4[2];
-    return (c & 2u) ? hi : lo;
+    ra = occ_lf_of(ea, loc_a);
+    rb = occ_lf_of(eb, loc_b);
 }
 
 // SA[row].  Full SA: one 8-byte gather (sa_access, fmidx.c:18-33).  Sampled SA (LRM_SA_SAMPLED=r): only rows
@@ -105,7 +96,7 @@ __device__ __forceinline__ uint64_t sa_locate(const LrmIndexView &ix, uint64_t r
         const ulonglong2 e3 = *reinterpret_cast<const ulonglong2 *>(&b->sym[3]);
         const uint32_t c = (uint32_t) ((e1.y >> r) & 1ull) | ((uint32_t) ((e2.y >> r) & 1ull) << 1) | ((uint32_t) ((e3.y >> r) & 1ull) * 3u);
         const ulonglong2 e = c == 0 ? e0 : c == 1 ? e1 : c == 2 ? e2 : e3;
-        row = c4_of(ix, c) + e.x + (uint64_t) __popcll(e.y & (~0ull >> (63u - r)));         // LF(row) = C[c] + rank(c, row)
+        row = occ_lf_of(e, row);                                        // LF(row) = C[c] + rank(c, row)
         ++t;
     }
     return ix.sa[row >> ix.sa_shift] + t;
@@ -160,10 +151,9 @@ __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t wi
     for (int i = left - 1; i >= 0; --i) {
         uint32_t c = (uint32_t) (win >> (2 * i)) & 3u;
         uint64_t ra, rb;
-        occ_rank2(ix, c, k - 1, l, ra, rb);
-        const uint64_t cc = c4_of(ix, c);
-        k = cc + ra + 1;
-        l = cc + rb;
+        occ_lf2(ix, c, k - 1, l, ra, rb);
+        k = ra + 1;
+        l = rb;
         if (k > l) break;
     }
     return k > l ? 0 : l - k + 1;
@@ -182,10 +172,9 @@ __global__ __launch_bounds__(256) void lcl_build_kernel(LrmIndexView ix, int hl,
         for (int i = ext - 1; i >= 0 && k <= l; --i) {
             const uint32_t c = (uint32_t) (code >> (2 * i)) & 3u;
             uint64_t ra, rb;
-            occ_rank2(ix, c, k - 1, l, ra, rb);
-            const uint64_t cc = c4_of(ix, c);
-            k = cc + ra + 1;
-            l = cc + rb;
+            occ_lf2(ix, c, k - 1, l, ra, rb);
+            k = ra + 1;
+            l = rb;
         }
         if (k <= l) {
             const uint64_t cnt = l - k + 1;

@@ -19,14 +19,14 @@ def _header(blob):
     return {k: (int(v) if np.ndim(v) == 0 else v.astype(np.uint64)) for k, v in f.items()}
 
 
-def _model_occ(bwt, n_blocks):
+def _model_occ(bwt, n_blocks, c4):
     L = len(bwt)
     out = np.zeros((n_blocks, 4, 2), dtype=np.uint64)
     pad = np.zeros(n_blocks * 64, dtype=np.uint8)
     pad[:L] = bwt
     for c, ch in enumerate(b"ACGT"):
         is_c = (pad == ch).reshape(n_blocks, 64)
-        out[:, c, 0] = np.concatenate([[0], np.cumsum(is_c.sum(axis=1))[:-1]])
+        out[:, c, 0] = np.uint64(c4[c]) + np.concatenate([[0], np.cumsum(is_c.sum(axis=1))[:-1]]).astype(np.uint64)   # C[c] + prefix
         out[:, c, 1] = (is_c.astype(np.uint64) << np.arange(64, dtype=np.uint64)).sum(axis=1)
     return out
 
@@ -50,7 +50,9 @@ def test_image_matches_numpy_model(n, hlen):
     bwt = hi.bwt()
     assert h["dollar_row"] == int(np.nonzero(bwt == ord("$"))[0][0])
     occ = np.frombuffer(blob[h["off_occ"]:h["off_occ"] + h["n_blocks"] * 64].tobytes(), dtype="<u8").reshape(-1, 4, 2)
-    assert np.array_equal(occ, _model_occ(bwt, h["n_blocks"]))
+    c_arr = hi.c()
+    assert [int(x) for x in h["c4"]] == [int(c_arr[ord(ch)]) for ch in "ACGT"]
+    assert np.array_equal(occ, _model_occ(bwt, h["n_blocks"], h["c4"]))
     # lc: entry[code] = k | cnt << 40 with code = the 2-bit groups of the reference's index reversed
     lc = np.frombuffer(blob[h["off_lc"]:h["off_lc"] + h["lc_entries"] * 8].tobytes(), dtype="<u8")
     ref = hi.lc().reshape(-1, 2)
