@@ -218,7 +218,7 @@ __device__ __forceinline__ uint64_t read_window(const uint64_t *__restrict__ wor
 }
 
 // ----------------------------------------------------------------------------------------
-// K1 seed_search: one lane per seed, SS_ITEMS seeds per workgroup (8 per thread).  Work items of a read are
+// K1 seed_search: one lane per seed, SS_ITEMS seeds per workgroup (4 or 8 per thread).  Work items of a read are
 // (q, iter) with iter fastest, so the 64 lanes of a wavefront hold 64 CONSECUTIVE read positions.
 // Output: the SURVIVORS only (0 < rr < thres, ~25 % of the seeds of a noisy read), compact per (read, phase):
 //   rec [id][0 .. cnt[id])   k | rr << 40         recq[id][..]  seed ordinal q        (id = read*P + phase)
@@ -229,9 +229,11 @@ __device__ __forceinline__ uint64_t read_window(const uint64_t *__restrict__ wor
 // and every vote tier re-read all of it.)  The order of a list does not matter: the first-seen order key of a hit,
 // (q << tbits) | t, is a property of the hit.
 // ----------------------------------------------------------------------------------------
-#ifndef SS_ITEMS
-#define SS_ITEMS 2048                  // seeds per workgroup (measured, tools/build_probe.py: 512 26.2 ms, 1024 25.5, 2048 25.0)
-#endif
+// SS_ITEMS seeds per workgroup (LDS lists of 12 B per seed; LRM_SS_ITEMS=1024|2048|4096 overrides the default 2048).
+// Measured per 1-Gbp step [r2]: E. coli-sized text 512 / 1024 / 2048 / 4096 seeds: 26.2 / 25.5 / 24.9 / 31.6 ms;
+// GRCh38-sized text 1024 / 2048 / 4096: 44.0 / 40.9 / 42.7 ms.  More resident wavefronts (1024: eight workgroups per
+// CU instead of six) do NOT help: the kernel is bound by the memory system's random-request rate, not by latency.
+template <int SS_ITEMS>
 __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const uint64_t *__restrict__ reads2,
                                                           uint64_t words_per_read,
                                                           const uint32_t *__restrict__ lens,
@@ -915,11 +917,14 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
         if (lo > hi) break;
         int np = hi - lo + 1;
         const uint8_t *dec = round == 0 || single ? nullptr : ws->d_decided;
-        uint32_t bpr = (uint32_t) (((uint64_t) np * cap_q + SS_ITEMS - 1) / SS_ITEMS);
+        uint32_t ss_items = 2048u;
+        if (const char *e = getenv("LRM_SS_ITEMS")) { const int v = atoi(e); if (v == 1024 || v == 2048 || v == 4096) ss_items = (uint32_t) v; }   // tuning knob
+        uint32_t bpr = (uint32_t) (((uint64_t) np * cap_q + ss_items - 1) / ss_items);
         uint64_t blocks = n * bpr;
         if (blocks > 0x7fffffffull) { lrm_set_error("seed_search grid too large: split the batch"); return -1; }
         lrm_time_begin(ws, LRM_K_SEED_SEARCH, stream);
-        hipLaunchKernelGGL(seed_search_kernel, dim3((uint32_t) blocks), dim3(256), 0, stream, idx->view,
+        auto sk = ss_items == 1024u ? seed_search_kernel<1024> : ss_items == 4096u ? seed_search_kernel<4096> : seed_search_kernel<2048>;
+        hipLaunchKernelGGL(sk, dim3((uint32_t) blocks), dim3(256), 0, stream, idx->view,
                            ws->d_reads2, wpr, d_lens, dec, n, (int) seed_len, thres, lo, hi, cap_q, bpr,
                            ws->d_rec, ws->d_recq, ws->d_cnt, ws->d_hcount);
         lrm_time_end(ws, stream);

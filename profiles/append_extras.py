@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Appends the sections of profiles/<tag>/README.md that do not come from profiles/collect.sh: the GRCh38-sized run
+(`bench_grch38_100k_x_10kbp.json/.log`), the large-index test log and the pointer to the probe outputs.
+Run after profiles/summarize_pmc.py (which rewrites the README from scratch)."""
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), tag)
+d = json.loads(open(os.path.join(dst, "bench_grch38_100k_x_10kbp.json")).read().strip().splitlines()[-1])
+ix, iso, pc, rf, cpu = d["index"], d["isolated"], d["pcie_inclusive"], d["roofline"], d["cpu_baseline"]
+out = ["", "## GRCh38-sized text on one GPU (`bench_grch38_100k_x_10kbp.json`, `.log`)", "",
+       "`python bench.py --ref-len 3099750718 --steps %d --warmup %d --cpu-seconds 8`: synthetic 3,099,750,718 bp reference "
+       "(no FASTA on the box), L = %d rows; index built on the box's %d-CPU share in %.1f s (peak RSS %.1f GB), %.1f GiB "
+       "image packed + uploaded in %.1f s, 32 GiB long seed table derived on the device."
+       % (d["steps"], d["warmup"], ix["rows"], ix["host_cpus"], ix["build_s"], ix["peak_rss_gb"], ix["image_bytes"] / 2**30,
+          ix["pack_upload_s"]), "", "| | |", "|---|---|",
+       "| `value` (HBM-resident, 3 streams) | **%.2f Gbp/s**, %.1f ms per 1-Gbp step |" % (d["value"], d["ms_per_step"]),
+       "| serialized replay | %.2f Gbp/s, %.1f ms per step |" % (iso["value"], iso["ms_per_step"]),
+       "| `pcie_inclusive` (`lrm_map_batch`, pinned / pageable) | %.2f / %.2f Gbp/s |" % (pc["pinned"]["value"], pc["pageable"]["value"]),
+       "| `seed_search` | %.2f ms per launch (one launch per step), %.2f TB/s algorithmic = **%.2f of 8 TB/s** (%.0f B per read base in "
+       "the reference layout) |" % (rf["avg_launch_ms"], rf["achieved"] / 1e3, rf["frac"], d["algorithmic_bytes_per_base"]["seed_search"]),
+       "| CPU oracle, %d threads / 1 thread | %.5f / %.6f Gbp/s (x%.0f / x%.0f for `value`) |"
+       % (cpu["cores"], cpu["value"], cpu["one_thread"]["value"], d["value"] / cpu["value"], d["value"] / cpu["one_thread"]["value"]),
+       "| checked in the run | %s |" % pc["checked"], "", "Serialized per-kernel table of that run:", "",
+       "| kernel | launches | avg ms |", "|---|---|---|"]
+for k, v in iso["kernels"].items():
+    out.append("| %s | %d | %.3f |" % (k, v["launches"], v["avg_ms"]))
+out += ["", "`large_test.log`: `tests/test_gpu_large.py` (4.4 G rows: loci, rows and SA values beyond 2^32 end to end against the oracle).",
+        "", "`probes/`: raw outputs of the tuning probes behind the \"measured and rejected\" notes of `DESIGN.md` (its README lists them)."]
+with open(os.path.join(dst, "README.md"), "a") as f:
+    f.write("\n".join(out) + "\n")
