@@ -368,9 +368,12 @@ __device__ __forceinline__ uint32_t bucket_hash(uint64_t bucket) {
 
 // One slot = {min key of the bucket, count, min order key}: the bucket is key >> 4 (histo.c:26-28) and the entry's
 // key is the minimum key added to it (histo.c:45-49), so the smallest key IS the slot's identity and its payload.
+// Count and order key share one 8-byte word, `count << 32 | ~first` -- the slot's rank in the stable top-2 as it
+// stands: the count is a 32-bit atomic add on the high dword, the first-seen order a 32-bit atomic max on the low
+// one, and clearing or scanning a slot is one 8-byte LDS access instead of two 4-byte ones.
 struct VoteTable {
     uint64_t *key;
-    uint32_t *count, *first;
+    uint64_t *cf;
     uint32_t slots;
 };
 
@@ -385,8 +388,9 @@ __device__ __forceinline__ bool vote_insert(const VoteTable &t, uint64_t key, ui
         const unsigned long long prev = atomicCAS((unsigned long long *) &t.key[slot], EMPTY_KEY, key);
         if (prev == EMPTY_KEY || (prev >> 4) == bucket) {
             if (prev != EMPTY_KEY && key < prev) atomicMin((unsigned long long *) &t.key[slot], (unsigned long long) key);
-            atomicAdd(&t.count[slot], n);
-            atomicMin(&t.first[slot], order);
+            uint32_t *cf = reinterpret_cast<uint32_t *>(&t.cf[slot]);
+            atomicAdd(cf + 1, n);                              // count
+            atomicMax(cf, 0xFFFFFFFFu - order);                // ~(min order key)
             return true;
         }
         slot = slot + 1 == t.slots ? 0 : slot + 1;
@@ -446,7 +450,7 @@ __device__ __forceinline__ Top2 table_top2(const VoteTable &t, uint32_t tid) {
     uint64_t k1 = 0, k2 = 0;
     uint32_t s1 = 0, s2 = 0;
     for (uint32_t s = tid; s < t.slots; s += NT) {
-        const uint64_t k = ((uint64_t) t.count[s] << 32) | (uint64_t) (0xFFFFFFFFu - t.first[s]);
+        const uint64_t k = t.cf[s];
         if (k > k1) { k2 = k1; s2 = s1; k1 = k; s1 = s; }
         else if (k > k2) { k2 = k; s2 = s; }
     }
@@ -523,7 +527,7 @@ __device__ __forceinline__ bool vote_hits(const LrmIndexView &ix, const VoteTabl
 struct WaveLds {
     uint64_t key[T1_SLOTS];
     uint64_t srec[T1_LIMIT / 2];             // repeat seeds have >= 2 hits each
-    uint32_t count[T1_SLOTS], first[T1_SLOTS];
+    uint64_t cf[T1_SLOTS];
     uint32_t off[T1_LIMIT / 2 + 4];
     uint32_t sq[T1_LIMIT / 2];
 };
@@ -533,7 +537,7 @@ __device__ __forceinline__ void vote_item_wave(const LrmIndexView &ix, const uin
                                                const uint32_t *__restrict__ recq, uint32_t cnt, uint32_t H,
                                                uint32_t iter, uint32_t P, uint32_t tbits, int lane, WaveLds &L,
                                                LrmPhaseRes *out, uint32_t load) {
-    VoteTable t = {L.key, L.count, L.first, 0};
+    VoteTable t = {L.key, L.cf, 0};
     {   // clear / scan only as much of the table as this item can fill (<= 75 % load)
         const uint32_t eff = H * 100u / load + 64;
         t.slots = eff < (uint32_t) T1_SLOTS ? eff : (uint32_t) T1_SLOTS;
@@ -547,7 +551,7 @@ __device__ __forceinline__ void vote_item_wave(const LrmIndexView &ix, const uin
         e[u] = s < cnt ? rec[s] : 0ull;
         qq[u] = s < cnt ? recq[s] : 0u;
     }
-    for (uint32_t s = lane; s < t.slots; s += 64) { t.key[s] = EMPTY_KEY; t.count[s] = 0; t.first[s] = EMPTY32; }
+    for (uint32_t s = lane; s < t.slots; s += 64) { t.key[s] = EMPTY_KEY; t.cf[s] = 0; }
     uint32_t run = 0, nbig = 0;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -589,7 +593,7 @@ __device__ __forceinline__ void vote_item_wave(const LrmIndexView &ix, const uin
 struct BlockLds {
     uint64_t key[T3_SLOTS];
     uint64_t srec[T3_CHUNK];
-    uint32_t count[T3_SLOTS], first[T3_SLOTS];
+    uint64_t cf[T3_SLOTS];
     uint32_t off[T3_CHUNK + 4];
     uint32_t sq[T3_CHUNK];
 };
@@ -604,7 +608,7 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
                                                 uint32_t kc_cap) {
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     const int lane = (int) (tid & 63);
-    VoteTable t = {L.key, L.count, L.first, slots};
+    VoteTable t = {L.key, L.cf, slots};
     const uint32_t passes = (H + limit - 1) / limit;
     // Items that need several passes (ultra-long reads: ~3500 hits, five passes): the first pass writes every hit's
     // {key, order key} to this workgroup's slice of a global scratch, and the later passes stream them back
@@ -618,7 +622,7 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
     }
     PhaseTop best = {};
     for (uint32_t pass = 0; pass < passes; ++pass) {
-        for (uint32_t s = tid; s < t.slots; s += 256) { t.key[s] = EMPTY_KEY; t.count[s] = 0; t.first[s] = EMPTY32; }
+        for (uint32_t s = tid; s < t.slots; s += 256) { t.key[s] = EMPTY_KEY; t.cf[s] = 0; }
         bool ok = true;
         if (cache && pass > 0) {
             __syncthreads();                                   // table cleared

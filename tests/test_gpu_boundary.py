@@ -255,3 +255,39 @@ def test_concurrent_calls_on_one_handle_and_on_two(ont, gpu):
         o.close()
     assert not errs, errs
     assert len(out) == 4
+
+
+def test_map_batch_degenerate_and_ragged_batches(gpu):
+    """The fused call on the shapes a host loop can hand over: an empty batch, a batch of one, only empty reads, the
+    ragged scenario (empty, shorter than a seed, exactly seed_len, ...) in rows WIDER than max_len + 1 with op rows
+    wider than 2 * max_len -- all against the oracle, bytes outside the used part of a row untouched."""
+    sc = workloads.scenario("ragged")
+    di = index.DeviceIndex.upload(sc["hi"], gpu)
+    oi = orc.OracleIndex.from_host_index(sc["hi"])
+    try:
+        n, stride = sc["reads"].shape
+        got = mapper.map_batch(di, np.zeros((0, 8), dtype=np.uint8), np.zeros(0, dtype=np.uint32))
+        assert len(got["best"]) == 0 and len(got["score"]) == 0
+        wide = np.full((n, stride + 16), 0x5A, dtype=np.uint8)           # caller rows with slack behind the NUL padding
+        wide[:, :stride] = sc["reads"]
+        store = np.full((n, 2 * (stride - 1) + 40), 0xA5, dtype=np.uint8)
+        best, _ = oi.seed_batch(sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+        r_cpu = sc["reads"].copy()
+        ext = oi.extend_batch(r_cpu, sc["lens"], best)
+        got = mapper.map_batch(di, wide, sc["lens"], sc["seed_len"], sc["thres"], store=store)
+        assert np.array_equal(got["best"], best)
+        _assert_ext_equal(got, ext, n, "ragged, wide rows")
+        assert np.array_equal(wide[:, :stride], r_cpu) and (wide[:, stride:] == 0x5A).all()
+        for i in range(n):
+            assert (store[i, int(ext["n_ops"][i]):] == 0xA5).all(), i      # nothing written beyond n_cigar_op
+        for k in (1, 2):                                                   # a batch of one or two reads
+            r1 = sc["reads"][20:20 + k].copy()
+            g1 = mapper.map_batch(di, r1, sc["lens"][20:20 + k], sc["seed_len"], sc["thres"])
+            assert np.array_equal(g1["best"], best[20:20 + k]) and np.array_equal(g1["score"], ext["score"][20:20 + k])
+        z = np.zeros((5, 33), dtype=np.uint8)                              # only empty reads: no seeds, 'I' tails of length 0
+        gz = mapper.map_batch(di, z, np.zeros(5, dtype=np.uint32), sc["seed_len"], sc["thres"])
+        bz, _ = oi.seed_batch(z, np.zeros(5, dtype=np.uint32), sc["seed_len"], sc["thres"])
+        ez = oi.extend_batch(z.copy(), np.zeros(5, dtype=np.uint32), bz)
+        assert np.array_equal(gz["best"], bz) and np.array_equal(gz["score"], ez["score"]) and np.array_equal(gz["meta_r"], ez["meta_r"])
+    finally:
+        di.close()
