@@ -131,15 +131,20 @@ def test_largest_tile_and_band(ref3):
     _compare(di, oi, r["reads"], r["lens"], (512, 0, 1024))
 
 
-def test_revcomp_in_place_ragged_rows(ref3):
+@pytest.mark.parametrize("alphabet,impl", [(b"ACGTacgtNRY-", None), (b"ACGTacgtNRY-", "4"), (b"ACGT", "4")])
+def test_revcomp_in_place_ragged_rows(ref3, monkeypatch, alphabet, impl):
     """`_rev_comp_in_place` (alnmain.c:27-60) on rows of every alignment: lengths 1..70, around the kernel's
     4096-base span boundaries, odd and even, with lower-case and non-ACGT bytes (-> 'N'), every read placed on the
-    reverse strand by its locus; forward-strand rows in between must stay untouched."""
+    reverse strand by its locus; forward-strand rows in between must stay untouched.  With LRM_GACT_IMPL=4 the same
+    rows also go through the planar packer of the bit-sliced kernel (16 bases per lane from unaligned rows; reads with
+    a byte other than ACGT are flagged there and fall back to the byte kernel)."""
+    if impl:
+        monkeypatch.setenv("LRM_GACT_IMPL", impl)
     seqs, hi, di, oi = ref3
     lens = list(range(1, 71)) + [4095, 4096, 4097, 8191, 8192, 8193, 8223, 8224, 8225, 12289, 16384, 16399, 20001]
     n, mx = len(lens), max(lens)
     rng = np.random.default_rng(5)
-    reads = np.frombuffer(b"ACGTacgtNRY-", dtype=np.uint8)[rng.integers(0, 12, size=(n, mx + 1))].copy()
+    reads = np.frombuffer(alphabet, dtype=np.uint8)[rng.integers(0, len(alphabet), size=(n, mx + 1))].copy()
     lens = np.array(lens, dtype=np.uint32)
     for i in range(n):
         reads[i, lens[i]:] = 0
