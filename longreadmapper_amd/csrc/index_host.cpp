@@ -195,7 +195,7 @@ static bool pack_text(const char *text, uint64_t L, PackedText &t) {
     t.w.assign(n / 32 + 4, 0);
     int bad = 0;
     const uint64_t nwords = (n + 31) / 32;
-#pragma omp parallel for schedule(static) reduction(| : bad)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(static) reduction(| : bad)
     for (uint64_t wi = 0; wi < nwords; ++wi) {
         uint64_t v = 0;
         const uint64_t lo = wi * 32, hi = lo + 32 < n ? lo + 32 : n;
@@ -237,7 +237,7 @@ static int sa_build_bucketed(const PackedText &t, uint64_t L, lrm_ui40 *out, uin
     std::vector<uint64_t> cnt(NB + 1, 0);
     {
         std::vector<std::vector<uint64_t>> local((size_t) nth, std::vector<uint64_t>(NB, 0));
-#pragma omp parallel
+#pragma omp parallel num_threads(lrm_host_threads())
         {
             std::vector<uint64_t> &h = local[(size_t) omp_get_thread_num()];
 #pragma omp for schedule(static)
@@ -276,7 +276,7 @@ static int sa_build_bucketed(const PackedText &t, uint64_t L, lrm_ui40 *out, uin
         if (rows == 0) { g0 = g1; continue; }
         for (uint64_t bkt = g0; bkt < g1; ++bkt) cursor[bkt] = cnt[bkt] - base;
         // collect {key, position} of the group's suffixes: threads reserve space in small batches
-#pragma omp parallel
+#pragma omp parallel num_threads(lrm_host_threads())
         {
             constexpr int LB = 8;
             std::vector<KeyPos> lbuf((size_t) (g1 - g0) * LB);
@@ -309,7 +309,7 @@ static int sa_build_bucketed(const PackedText &t, uint64_t L, lrm_ui40 *out, uin
         tm.lap("sa: collect group");
         // sort every bucket: by key in cache, ties through the text
         uint64_t work = 0;
-#pragma omp parallel reduction(+ : work)
+#pragma omp parallel num_threads(lrm_host_threads()) reduction(+ : work)
         {
         std::vector<KeyPos> tmp;
 #pragma omp for schedule(dynamic, 1)
@@ -344,7 +344,7 @@ extern "C" int lrm_sa_build(const char *text, uint64_t L, lrm_ui40 *out) {
     if (text[L - 1] != '$') { lrm_set_error("text must end in '$'"); return -1; }
     {   // '$' must not occur inside the text
         uint64_t inner = ~0ull;
-#pragma omp parallel for schedule(static) reduction(min : inner)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(static) reduction(min : inner)
         for (uint64_t i = 0; i < L - 1; ++i) if (text[i] == '$' && i < inner) inner = i;
         if (inner != ~0ull) { lrm_set_error("'$' occurs inside the text (offset %llu)", (unsigned long long) inner); return -1; }
     }
@@ -369,13 +369,13 @@ extern "C" int lrm_sa_build(const char *text, uint64_t L, lrm_ui40 *out) {
     int K = 0;
     for (int c = 0; c < 256; ++c) map[c] = seen[c] ? K++ : -1;
     if (map[(unsigned char) '$'] != 0) { lrm_set_error("'$' is not the smallest byte of the text"); return -1; }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(static)
     for (uint64_t i = 0; i < L; ++i) s[i] = (uint8_t) map[(unsigned char) text[i]];
     uint64_t *sa64 = reinterpret_cast<uint64_t *>(out);          // ui40 slots are 8 bytes: value < 2^40, padding zeroed
     if (L < (1ull << 31) - 8) {
         std::vector<int32_t> sa((size_t) L);
         SaIs<int32_t>::run<uint8_t>(s.data(), sa.data(), (int32_t) L, (int32_t) (K - 1));
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(static)
         for (uint64_t i = 0; i < L; ++i) sa64[i] = (uint64_t) (uint32_t) sa[i];
     } else {
         // in place: SA-IS runs on the caller's 8-byte slots (int64), no second array
@@ -408,7 +408,7 @@ extern "C" int lrm_cat_from_seqs(const char *const *names, const char *const *se
         // the thread count), upper-casing (asindex.c:63-68)
         uint64_t bad_pos = ~0ull;
         const uint64_t rs0 = splitmix64(rs);
-#pragma omp parallel for schedule(static) reduction(min : bad_pos)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(static) reduction(min : bad_pos)
         for (uint64_t p = 0; p < n; ++p) {
             char c = seqs[i][p];
             if (c == 'n' || c == 'N') { uint64_t st = rs0 ^ (p * 0x9E3779B97F4A7C15ull); c = "ACGT"[splitmix64(st) & 3]; }
@@ -421,7 +421,7 @@ extern "C" int lrm_cat_from_seqs(const char *const *names, const char *const *se
             free(cat); lrm_mta_free(mta, nseq);
             return -1;
         }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(static)
         for (uint64_t p = 0; p < n; ++p) cat[off + n + p] = "TGCA"[dna_code(cat[off + n - 1 - p])];   // asindex.c:70-75
         off += 2 * n;
     }
@@ -456,7 +456,7 @@ extern "C" int lrm_host_index_build(const char *cat, uint64_t L, const lrm_mta_e
     if (!out->content || !out->sa.mem) { lrm_host_index_free(out); lrm_set_error("out of memory"); return -1; }
     {
         const uint64_t piece = 1ull << 22, np = (L + piece - 1) / piece;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(static)
         for (uint64_t i = 0; i < np; ++i) memcpy(out->content + i * piece, cat + i * piece, L - i * piece < piece ? L - i * piece : piece);
     }
     out->content[L] = 0;
@@ -486,7 +486,7 @@ extern "C" int lrm_host_index_build(const char *cat, uint64_t L, const lrm_mta_e
     f->c = (uint64_t *) calloc(256, sizeof(uint64_t));
     {
         uint64_t ca = 0, cc = 0, cg = 0, ct = 0, other = 0;
-#pragma omp parallel for schedule(static) reduction(+ : ca, cc, cg, ct, other)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(static) reduction(+ : ca, cc, cg, ct, other)
         for (uint64_t i = 0; i < L - 1; ++i) {
             switch (cat[i]) { case 'A': ca++; break; case 'C': cc++; break; case 'G': cg++; break; case 'T': ct++; break; default: other++; }
         }
@@ -500,7 +500,7 @@ extern "C" int lrm_host_index_build(const char *cat, uint64_t L, const lrm_mta_e
     // BWT (fmidx.c:76-98)
     f->length = L;
     f->bwt = (char *) malloc(L + 1);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(static)
     for (uint64_t i = 0; i < L; ++i) {
         const uint64_t v = ui40v(sa[i]);
         f->bwt[i] = v == 0 ? '$' : (pure ? "ACGT"[(pt.w[(v - 1) >> 5] >> (62 - 2 * ((v - 1) & 31))) & 3] : cat[v - 1]);
@@ -514,7 +514,7 @@ extern "C" int lrm_host_index_build(const char *cat, uint64_t L, const lrm_mta_e
     {   // segments of SEG sample intervals: counts per segment first, then every segment fills its samples
         const uint64_t R = (uint64_t) o_ratio, SEG = 1ull << 15, rows_per_seg = SEG * R, nseg = (L + rows_per_seg - 1) / rows_per_seg;
         std::vector<uint64_t> segc((nseg + 1) * 4, 0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(static)
         for (uint64_t sg = 0; sg < nseg; ++sg) {
             uint64_t c[4] = {0, 0, 0, 0};
             const uint64_t lo = sg * rows_per_seg, hi = lo + rows_per_seg < L ? lo + rows_per_seg : L;
@@ -522,7 +522,7 @@ extern "C" int lrm_host_index_build(const char *cat, uint64_t L, const lrm_mta_e
             for (int x = 0; x < 4; ++x) segc[(sg + 1) * 4 + x] = c[x];
         }
         for (uint64_t sg = 1; sg <= nseg; ++sg) for (int x = 0; x < 4; ++x) segc[sg * 4 + x] += segc[(sg - 1) * 4 + x];
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(static)
         for (uint64_t sg = 0; sg < nseg; ++sg) {
             uint64_t run[4] = {segc[sg * 4], segc[sg * 4 + 1], segc[sg * 4 + 2], segc[sg * 4 + 3]};
             const uint64_t lo = sg * rows_per_seg, hi = lo + rows_per_seg < L ? lo + rows_per_seg : L;
@@ -539,7 +539,7 @@ extern "C" int lrm_host_index_build(const char *cat, uint64_t L, const lrm_mta_e
     f->csa_ratio = 4;
     f->csa_len = L / 4 + 1;
     f->csa = (uint64_t *) calloc(f->csa_len, sizeof(uint64_t));
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(static)
     for (uint64_t i = 0; i < f->csa_len; ++i) f->csa[i] = i * 4 < L ? ui40v(sa[i * 4]) : 0;
 
     tm.lap("csa");
@@ -563,7 +563,7 @@ extern "C" int lrm_host_index_build(const char *cat, uint64_t L, const lrm_mta_e
     };
     // one text access per row: the codes of a block of rows first, then the interval boundaries inside it
     const uint64_t RB = 1ull << 16, nrb = (L + RB - 1) / RB;
-#pragma omp parallel
+#pragma omp parallel num_threads(lrm_host_threads())
     {
         std::vector<uint64_t> codes(RB + 2);
 #pragma omp for schedule(dynamic, 4)

@@ -193,7 +193,7 @@ extern "C" char *lrm_sam_format(const lrm_read_batch *reads, const lrm_mta_entry
                                 const int *meta_r, uint64_t n, uint64_t *len_out) {
     // Every thread formats a contiguous range of reads into its own buffer (no snprintf on the hot path: a 10 kbp ONT
     // read has ~2000 CIGAR runs), then the parts are copied to their offsets of one allocation in parallel.
-    const int nt = omp_get_max_threads();
+    const int nt = lrm_host_threads();
     std::vector<std::string> parts((size_t) nt);
     std::vector<uint64_t> at((size_t) nt + 1, 0);
     char *out = nullptr;

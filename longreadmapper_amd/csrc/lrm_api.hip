@@ -10,6 +10,8 @@
 #include <vector>
 #include <algorithm>
 #include <dlfcn.h>
+#include <sched.h>
+#include <omp.h>
 #include "lrm_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -25,6 +27,28 @@ void lrm_set_error(const char *fmt, ...) {
     lrm_set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
 
 extern "C" const char *lrm_last_error(void) { return g_err; }
+int lrm_host_threads(void) {
+    static const int n = []() {
+        int m = omp_get_max_threads();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c >= 1 && c < m) m = c; }
+        long long quota = -1, period = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
+            char q[64];
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else {                                                                    // cgroup v1
+            FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+            if (fq && fp && fscanf(fq, "%lld", &quota) == 1 && fscanf(fp, "%lld", &period) == 1) {} else quota = -1;
+            if (fq) fclose(fq);
+            if (fp) fclose(fp);
+        }
+        if (quota > 0 && period > 0) { const int c = (int) (quota / period); if (c >= 1 && c < m) m = c; }
+        return m < 1 ? 1 : m;
+    }();
+    return n;
+}
+
 extern "C" int lrm_abi_version(void) { return LRM_ABI_VERSION; }
 
 extern "C" int lrm_device_count(void) {
@@ -112,7 +136,7 @@ struct BlobPacker {
         const uint64_t nseg = (L + SEG - 1) / SEG;
         seg_cnt.assign((nseg + 1) * 4, 0);
         uint64_t dollar = ~0ull, n_dollar = 0, bad_row = ~0ull;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : n_dollar) reduction(min : dollar, bad_row)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(dynamic, 4) reduction(+ : n_dollar) reduction(min : dollar, bad_row)
         for (uint64_t sg = 0; sg < nseg; ++sg) {
             const uint64_t lo = sg * SEG, hi = lo + SEG < L ? lo + SEG : L;
             uint64_t c[4] = {0, 0, 0, 0};
@@ -142,7 +166,7 @@ struct BlobPacker {
         lcx_thr = long_thr;
         std::vector<uint64_t> over;
         const uint64_t ne = h.lc_entries;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(static)
         for (uint64_t num = 0; num < ne; ++num) {
             const uint64_t k = lch->lc[2 * num], l = lch->lc[2 * num + 1];
             if (k == 0 && l == 0) continue;
@@ -178,7 +202,7 @@ struct BlobPacker {
         const uint64_t bps = SEG / LRM_OCC_ROWS;           // blocks per segment
         uint64_t bad = ~0ull;
         const uint64_t s0 = b0 / bps, s1 = (b0 + nb + bps - 1) / bps;
-#pragma omp parallel for schedule(dynamic, 1) reduction(min : bad)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(dynamic, 1) reduction(min : bad)
         for (uint64_t sg = s0; sg < s1; ++sg) {
             uint64_t run[4];
             const uint64_t nseg = (L + SEG - 1) / SEG;
@@ -209,7 +233,7 @@ struct BlobPacker {
     // lc entries [c0, c0 + n) in device order (LSB-first code): gathered from the reference's table
     void fill_lc(uint64_t c0, uint64_t n, uint64_t *dst) const {
         const int hl = lch->hlen;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(static)
         for (uint64_t i = 0; i < n; ++i) {
             const uint64_t num = rev_groups(c0 + i, hl);               // the permutation is an involution
             const uint64_t k = lch->lc[2 * num], l = lch->lc[2 * num + 1];
@@ -226,7 +250,7 @@ struct BlobPacker {
     // SA entries [e0, e0 + n) of the image: rows e*sa_ratio, as u64 (sa_use.h:27-29)
     void fill_sa(uint64_t e0, uint64_t n, uint64_t *dst) const {
         const uint64_t r = h.sa_ratio;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(static)
         for (uint64_t i = 0; i < n; ++i) {
             const lrm_ui40 &v = sa->mem[(e0 + i) * r];
             dst[i] = ((uint64_t) v.high << 32) | (uint64_t) v.low;
@@ -278,7 +302,7 @@ struct BlobPacker {
             if (!b) return -1;
             const uint64_t nc = o + n > L ? L - o : n;                 // the byte after the text is a NUL
             const uint64_t piece = 1ull << 20, np = (nc + piece - 1) / piece;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(lrm_host_threads()) schedule(static)
             for (uint64_t i = 0; i < np; ++i) {
                 const uint64_t po = i * piece, pl = nc - po < piece ? nc - po : piece;
                 memcpy(b + po, content + o + po, pl);

@@ -194,6 +194,10 @@ int lrm_lcl_prepare_index(lrm_index *idx);       // seed_kernels.hip: the long s
 void lrm_bs_free_index(lrm_index *idx);
 
 void lrm_set_error(const char *fmt, ...);
+// OpenMP team size for the library's host loops: omp_get_max_threads() capped by the CPUs this process may really use
+// (affinity mask, cgroup CPU quota) -- a GPU box hands a job 16 of its 256 hardware threads, and a team of 256 on a
+// quota of 16 is throttled to a crawl.  OMP_NUM_THREADS still lowers it.
+int lrm_host_threads(void);
 int lrm_require_device(int device);
 int lrm_workspace_create_parts(lrm_workspace **out, lrm_index *idx, uint64_t n_max, uint32_t max_len, uint32_t seed_len,
                                uint32_t thres, int parts);
