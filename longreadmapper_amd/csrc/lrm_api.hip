@@ -691,7 +691,8 @@ int lrm_workspace_create_parts(lrm_workspace **out, lrm_index *idx, uint64_t n_m
     ws->codes_cw = lrm_bs_code_words(max_len);
     ws->parts = parts;
     struct { void **p; uint64_t bytes; int part; } allocs[] = {
-        {(void **) &ws->d_reads2, n_max * ws->words_per_read * 8, LRM_WS_SEED},
+        {(void **) &ws->d_reads2, n_max * ws->words_per_read * 8 + 128, LRM_WS_SEED},   // + slack: seed_search's scalar window loads reach 6 words
+
         {(void **) &ws->d_rec, n_max * (uint64_t) ws->P * ws->cap_q * 8, LRM_WS_SEED},
         {(void **) &ws->d_recq, n_max * (uint64_t) ws->P * ws->cap_q * 4, LRM_WS_SEED},
         {(void **) &ws->d_cnt, n_max * (uint64_t) ws->P * 4, LRM_WS_SEED},

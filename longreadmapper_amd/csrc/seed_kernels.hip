@@ -268,14 +268,40 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
     const uint32_t len = lens[read];
     const uint32_t jl = len > (uint32_t) seed_len ? len - (uint32_t) seed_len : 0;   // alnmain.c:353 (fenced for len<s)
     const uint64_t *words = reads2 + read * words_per_read;
+    // When (nearly) all phases run in one launch the 64 lanes of a wavefront hold (nearly) consecutive read positions:
+    // their 32-base windows lie inside six consecutive words of the packed read, which the wavefront fetches with
+    // SCALAR loads (one request per wavefront through the scalar cache instead of 64 lane requests through the
+    // texture path) and every lane cuts its window out with selects and a funnel shift.
+    const bool dense_lanes = (uint32_t) P - np <= 1u;
 #pragma unroll 1
     for (uint32_t it = 0; it < SS_ITEMS / 256; ++it) {
         const uint32_t item = chunk * SS_ITEMS + it * 256 + tid;
         const uint32_t q = item / np, ph = item % np;
+        uint64_t W[6] = {0, 0, 0, 0, 0, 0};
+        uint32_t jw = 0;                                                       // first base of W[0]
+        if (dense_lanes) {
+            const uint32_t item0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) (item & ~63u));   // lane 0's item
+            const uint32_t q0 = item0 / np;
+            if (q0 < cap_q) {
+                const uint32_t j0 = (uint32_t) phase_lo + item0 % np + q0 * (uint32_t) P;
+                const uint64_t *wp = words + (j0 >> 5);                        // wave-uniform address
+                jw = j0 & ~31u;
+#pragma unroll
+                for (int e = 0; e < 6; ++e) W[e] = wp[e];
+            }
+        }
         if (q >= cap_q) break;
         const uint32_t j = (uint32_t) phase_lo + ph + q * (uint32_t) P;        // < 2^32: cap_q * P <= max_len + P
         if (j >= jl) continue;
-        const uint64_t win = read_window(words, j);
+        uint64_t win;
+        if (dense_lanes) {
+            const uint32_t rel = j - jw, wi = rel >> 5, sh = (rel & 31u) * 2u;  // rel <= 31 + 63 + 4: wi in 0..3
+            const uint64_t lo = wi == 0 ? W[0] : wi == 1 ? W[1] : wi == 2 ? W[2] : wi == 3 ? W[3] : W[4];
+            const uint64_t hi = wi == 0 ? W[1] : wi == 1 ? W[2] : wi == 2 ? W[3] : wi == 3 ? W[4] : W[5];
+            win = (lo >> sh) | ((hi << 1) << (63 - sh));
+        } else {
+            win = read_window(words, j);
+        }
         uint64_t k, l;
         const uint64_t rr = seed_one(ix, win, seed_len, k, l);
         if (rr > 0 && rr < (uint64_t) thres) {
