@@ -461,14 +461,27 @@ __device__ __forceinline__ uint32_t mask_rank(unsigned long long m) {
 // order key), so the stable top-2 is the two largest keys.  Every lane scans its slots, then two max-reductions.
 struct Top2 { uint64_t k1, k2; uint32_t s1, s2; };
 
+// max over the 64 lanes, returned in every lane: the prefix-max runs on the DPP network like wave_incl_scan (row
+// shifts inside the rows of 16, then row_bcast:15 / row_bcast:31), lane 63 ends up with the maximum and two readlanes
+// broadcast it.  (The first version was a butterfly of __shfl_xor: twelve ds_bpermute per reduction, a third of the
+// LDS instructions of a small vote item.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_max_step(uint64_t v) {
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) (uint32_t) v, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t hi = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) (uint32_t) (v >> 32), CTRL, ROW_MASK, 0xf, false);
+    const uint64_t o = ((uint64_t) hi << 32) | lo;                 // 0 where the lane has no source: the identity of max
+    return o > v ? o : v;
+}
 __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const uint32_t lo = __shfl_xor((uint32_t) v, m), hi = __shfl_xor((uint32_t) (v >> 32), m);
-        const uint64_t o = ((uint64_t) hi << 32) | lo;
-        v = o > v ? o : v;
-    }
-    return v;
+    v = dpp_max_step<0x111, 0xf>(v);      // row_shr:1
+    v = dpp_max_step<0x112, 0xf>(v);      // row_shr:2
+    v = dpp_max_step<0x114, 0xf>(v);      // row_shr:4
+    v = dpp_max_step<0x118, 0xf>(v);      // row_shr:8
+    v = dpp_max_step<0x142, 0xa>(v);      // row_bcast:15 -> rows 1, 3
+    v = dpp_max_step<0x143, 0xc>(v);      // row_bcast:31 -> rows 2, 3
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) v, 63);
+    const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (v >> 32), 63);
+    return ((uint64_t) hi << 32) | lo;
 }
 
 template <int NT>
