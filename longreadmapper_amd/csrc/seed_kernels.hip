@@ -765,7 +765,7 @@ void vote_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
                                                    uint32_t *__restrict__ kc_ord_all, uint32_t kc_cap,
                                                    LrmPhaseRes *__restrict__ phase_res, uint32_t *err_word) {
     __shared__ VoteLds lds;
-    __shared__ uint32_t g_H[VG_MAX], g_cnt[VG_MAX];
+    __shared__ uint32_t g_H[VG_MAX], g_cnt[VG_MAX], g_ph[VG_MAX];
     __shared__ uint64_t g_id[VG_MAX];
     __shared__ uint32_t s_wsum[12];
     __shared__ Top2 s_top[4];
@@ -787,25 +787,26 @@ void vote_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
     if (grp >= n_groups) break;
     if (tid < vg) {
         const uint64_t item = grp * vg + tid;
-        uint32_t H = 0, c = 0;
+        uint32_t H = 0, c = 0, ph = 0;
         uint64_t id = 0;
         if (item < n_items) {
             const uint64_t read = item / np;
-            id = read * (uint64_t) P + (uint64_t) phase_lo + (item % np);
+            ph = (uint32_t) phase_lo + (uint32_t) (item - read * np);        // the item's phase (kept: a 64-bit modulo per item and wavefront is ~150 instructions)
+            id = read * (uint64_t) P + (uint64_t) ph;
             if (!(decided && decided[read])) {
                 H = ghits[id];
                 c = gcnt[id];
                 if (H == 0) { LrmPhaseRes z = {0, 0, 0, 0, 0, 0}; phase_res[id] = z; }
             }
         }
-        g_H[tid] = H; g_cnt[tid] = c; g_id[tid] = id;
+        g_H[tid] = H; g_cnt[tid] = c; g_id[tid] = id; g_ph[tid] = ph;
     }
     __syncthreads();
     for (uint32_t g = wave; g < vg; g += 4) {                 // wavefront tier: four items at a time
         const uint32_t H = g_H[g];
         if (H == 0 || H > limit1) continue;
         const uint64_t id = g_id[g];
-        vote_item_wave<VOTE_U>(ix, rec + id * cap_q, recq + id * cap_q, g_cnt[g], H, (uint32_t) (id % P), P, tbits, lane,
+        vote_item_wave<VOTE_U>(ix, rec + id * cap_q, recq + id * cap_q, g_cnt[g], H, g_ph[g], P, tbits, lane,
                        lds.w[wave], &phase_res[id], load);
     }
     __syncthreads();
@@ -813,7 +814,7 @@ void vote_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
         const uint32_t H = g_H[g];
         if (H <= limit1) continue;
         const uint64_t id = g_id[g];
-        vote_item_block<VOTE_U>(ix, rec + id * cap_q, recq + id * cap_q, g_cnt[g], H, (uint32_t) (id % P), P, tbits, slots3,
+        vote_item_block<VOTE_U>(ix, rec + id * cap_q, recq + id * cap_q, g_cnt[g], H, g_ph[g], P, tbits, slots3,
                         limit3, lds.b, s_wsum, s_top, &phase_res[id], err_word, load, kc_key, kc_ord, kc_cap);
         __syncthreads();
     }
