@@ -261,8 +261,10 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
     // survivors of the table lookup into fewer wavefronts (+8 %), and searching 2 / 4 of the lane's seeds TOGETHER
     // (independent chains per lane, all rank gathers of a step in flight at once: 43.4 / 56.7 ms per step against
     // 29.0 [r2]): a wavefront of one-seed lanes stops as soon as its 64 neighbouring seeds are dead, a wavefront of
-    // interleaved chains runs until its longest chain ends, and 7.4 G wave-instructions of 64-bit index arithmetic
-    // per Gbp are a third of the kernel's time -- it is not bound by memory latency alone.  Also measured [r2]: a
+    // interleaved chains runs until its longest chain ends.  What binds the kernel is the memory system's rate of
+    // random requests (56 G 64-byte L2 misses per second on the small text): neither more resident wavefronts (see
+    // SS_ITEMS) nor fewer vector instructions (7.1 -> 5.0 G per Gbp with C[] folded into the occ prefixes and the
+    // scalar window loads: -2.5 %) move it much.  Also measured [r2]: a
     // 2 MiB presence bitmap of the 12-mers in front of the table lookup (57 % of the seeds die on an L2 hit instead of
     // fetching a table line): 27.3 vs 27.5 ms, not kept; non-temporal loads for the one-touch table lines: 31.7 ms.
     const uint32_t len = lens[read];
