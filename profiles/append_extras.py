@@ -27,6 +27,15 @@ out = ["", "## GRCh38-sized text on one GPU (`bench_grch38_100k_x_10kbp.json`, `
        "| kernel | launches | avg ms |", "|---|---|---|"]
 for k, v in iso["kernels"].items():
     out.append("| %s | %d | %.3f |" % (k, v["launches"], v["avg_ms"]))
+for f, what in (("bench_ecoli_131072_reads.json", "E. coli-sized text, 131,072 x 10 kbp ONT reads per step"),
+                ("bench_chr1_pacbio15k_131072_reads.json", "human-chr1-sized text, 131,072 x 15 kbp PacBio-CLR reads per step")):
+    fp = os.path.join(dst, f)
+    if os.path.exists(fp):
+        e = json.loads(open(fp).read().strip().splitlines()[-1])
+        out += ["", "`%s`: %s (two wavefronts of the lane-per-read extension on every SIMD): **%.2f Gbp/s** HBM-resident, %.2f serialized, "
+                "%.2f / %.2f PCIe-inclusive (pinned / pageable), extension %.1f TCUPS."
+                % (f, what, e["value"], e["isolated"]["value"], e["pcie_inclusive"]["pinned"]["value"], e["pcie_inclusive"]["pageable"]["value"],
+                   e["isolated"]["roofline_gact"]["gcups"] / 1e3)]
 out += ["", "`large_test.log`: `tests/test_gpu_large.py` (4.4 G rows: loci, rows and SA values beyond 2^32 end to end against the oracle).",
         "", "`probes/`: raw outputs of the tuning probes behind the \"measured and rejected\" notes of `DESIGN.md` (its README lists them)."]
 with open(os.path.join(dst, "README.md"), "a") as f:
