@@ -36,6 +36,8 @@ for f, what in (("bench_ecoli_131072_reads.json", "E. coli-sized text, 131,072 x
                 "%.2f / %.2f PCIe-inclusive (pinned / pageable), extension %.1f TCUPS."
                 % (f, what, e["value"], e["isolated"]["value"], e["pcie_inclusive"]["pinned"]["value"], e["pcie_inclusive"]["pageable"]["value"],
                    e["isolated"]["roofline_gact"]["gcups"] / 1e3)]
+out += ["", "`pmc_grch38_seed_vote.json`: FETCH_SIZE and TCC_HIT/MISS of `seed_search` and `vote` on the GRCh38-sized workload (own `--pmc` passes): "
+        "seed_search fetches 128 GB per launch (2.04 G L2 misses x 64 B, L2 hit rate 25 %) in 41.7 ms = 3.1 TB/s of random 64-byte lines."]
 out += ["", "`large_test.log`: `tests/test_gpu_large.py` (4.4 G rows: loci, rows and SA values beyond 2^32 end to end against the oracle).",
         "", "`probes/`: raw outputs of the tuning probes behind the \"measured and rejected\" notes of `DESIGN.md` (its README lists them)."]
 with open(os.path.join(dst, "README.md"), "a") as f:
