@@ -184,18 +184,33 @@ __global__ __launch_bounds__(256) void lcl_build_kernel(LrmIndexView ix, int hl,
     out[code] = e;
 }
 
-// LRM_LC_LONG: 0 = off, 13..16 = that k-mer length, unset = automatic:
+// LRM_LC_LONG: 0 = off, 13..17 = that k-mer length, unset = automatic:
+//   17 (128 GiB) on GRCh38-scale texts (>= 2^31 rows) when that much HBM is free with 64 GiB to spare: a random 16-mer
+//      occurs in a 6.2 G-row text with p = 0.76, a 17-mer with 0.30, so most noisy seeds die in the lookup instead of
+//      one HBM-random step later: seed_search 40.6 -> 32.4 ms per Gbp on the GRCh38-sized text [r2];
 //   16 (32 GiB) once the occ table is far beyond the caches -- every backward step is then an HBM-random request:
 //      -32 % seed_search time on a chr1-sized text [r1];
 //   13 (512 MiB) on small texts: one step less per seed from a table that still mostly sits in the Infinity Cache:
 //      -2.7 % on the E. coli-sized text [r2] (14, 2 GiB, loses 2 %: its lookups go to HBM).
+// A table that does not fit falls back to the next smaller choice (17 -> 16 -> none): results never depend on it.
 int lrm_lcl_prepare_index(lrm_index *idx) {
     int hl = idx->view.length >= (1ull << 26) ? 16 : 13;
-    if (const char *e = getenv("LRM_LC_LONG")) hl = atoi(e);
-    if (hl <= idx->view.hlen || hl > 16 || idx->view.length < 2) return 0;
+    bool automatic = true;
+    if (idx->view.length >= (1ull << 31)) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= ((8ull << 34) + (64ull << 30))) hl = 17;
+    }
+    if (const char *e = getenv("LRM_LC_LONG")) { hl = atoi(e); automatic = false; }
+    if (hl <= idx->view.hlen || hl > 17 || idx->view.length < 2) return 0;
     uint64_t *d = nullptr;
-    const uint64_t entries = 1ull << (2 * hl);
-    if (hipMalloc(&d, entries * 8) != hipSuccess) { (void) hipGetLastError(); return 0; }     // no room: the reference's table alone
+    uint64_t entries = 1ull << (2 * hl);
+    while (hipMalloc(&d, entries * 8) != hipSuccess) {               // no room: a smaller table, or the reference's table alone
+        (void) hipGetLastError();
+        d = nullptr;
+        if (!(automatic && hl == 17)) return 0;
+        hl = 16;
+        entries = 1ull << (2 * hl);
+    }
     const uint64_t blocks = entries / 256, chunk = 1ull << 22;         // 2^30 threads per launch (grid limit 2^32)
     for (uint64_t b0 = 0; b0 < blocks; b0 += chunk) {
         const uint64_t nb = blocks - b0 < chunk ? blocks - b0 : chunk;
