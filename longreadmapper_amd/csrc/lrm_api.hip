@@ -385,7 +385,7 @@ static int make_handle(lrm_index **out, void *d_blob, uint64_t bytes, int device
     ix->view.sa_len = h.sa_len; ix->view.con_len = h.con_len;
     for (int i = 0; i < 4; ++i) ix->view.c4[i] = h.c4[i];
     ix->view.hlen = h.hlen; ix->view.mta_len = h.mta_len;
-    ix->view.lcl = nullptr; ix->view.hl = 0;
+    ix->view.lcl = nullptr; ix->view.hl = 0; ix->view.lcl_pair = 0; ix->view.pad_ = 0;
     ix->view.sa_shift = 0;
     for (uint64_t r = h.sa_ratio > 1 ? h.sa_ratio : 1; r > 1; r >>= 1) ix->view.sa_shift++;
     ix->n_peers = 1;

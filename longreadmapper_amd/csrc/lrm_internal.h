@@ -74,6 +74,8 @@ struct LrmIndexView {
     const uint64_t *lcl;      // optional LONG table (hl-mers, hl > hlen), built on the device from lc + FM steps; null = unused
     int32_t hl;
     int32_t sa_shift;         // log2 of the SA sampling ratio (0: every row is stored)
+    int32_t lcl_pair;         // long table in PAIR-LINE layout (seed_kernels.hip): the lookups of two neighbouring seeds share a 64-byte line
+    int32_t pad_;
 };
 
 struct LrmHostCtx;            // lrm_host.hip: per-handle state of the host-buffer entry points

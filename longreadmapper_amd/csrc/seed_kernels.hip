@@ -120,7 +120,8 @@ __device__ __forceinline__ void lc_lookup(const LrmIndexView &ix, uint64_t code,
 // lc_aln (lchash.c:89-104) + fmi_aln (fmidx.c:295-313) on the packed read.
 // win: bases j.. of the read, 2 bits each, LSB first.  Returns rr; k,l as the reference
 // leaves them (also on failure).
-__device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t win, int seed_len,
+// jpar: parity of the seed's read position (only the pair-line layout of the long table looks at it).
+__device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t win, int seed_len, uint32_t jpar,
                                              uint64_t &k, uint64_t &l) {
     int left = seed_len - ix.hlen;
     bool looked_up = false;
@@ -130,7 +131,17 @@ __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t wi
         // instead of 1 + 2(hl - hlen).  The kernel is bound by the number of requests, and most seeds of a noisy
         // read die inside their last hl bases.
         const int left2 = seed_len - ix.hl;
-        const uint64_t e = ix.lcl[(win >> (2 * left2)) & ((1ull << (2 * ix.hl)) - 1ull)];
+        uint64_t at = (win >> (2 * left2)) & ((1ull << (2 * ix.hl)) - 1ull);          // the seed's last hl bases, first base lowest
+        if (ix.lcl_pair) {
+            // PAIR-LINE layout: one 64-byte line per (hl-1)-mer S holds the entries of its four left extensions a.S and
+            // of its four right extensions S.b.  The seed at an even read position j looks its hl-mer up as a.S, the seed
+            // at j + 1 as S.b with the SAME S (its hl-mer without its last base = the hl-mer of j without its first):
+            // the two lanes of neighbouring positions read one line, and the texture path merges them into one request.
+            const uint64_t smask = (1ull << (2 * (ix.hl - 1))) - 1ull;
+            at = (jpar & 1u) ? ((at & smask) << 3) + 4u + (at >> (2 * (ix.hl - 1)))
+                             : ((at >> 2) << 3) + (at & 3u);
+        }
+        const uint64_t e = ix.lcl[at];
         if ((e >> 40) != 0xFFFFFFull) {                               // (marker: interval too long for 24 bits)
             if (e == 0) { k = 0; l = 0; return 0; }                   // dead by its hl-th base; k, l are dead values then
             k = e & ((1ull << 40) - 1ull);
@@ -159,67 +170,78 @@ __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t wi
     return k > l ? 0 : l - k + 1;
 }
 
-// long table: one lane per hl-mer; the 4^(hl-hlen) extensions of one hlen-mer are contiguous
-__global__ __launch_bounds__(256) void lcl_build_kernel(LrmIndexView ix, int hl, uint64_t *__restrict__ out,
-                                                        uint64_t code0) {
-    const uint64_t code = code0 + (uint64_t) blockIdx.x * 256 + threadIdx.x;
+// entry of the long table for one hl-mer (code: first base lowest): the lc entry of its last hlen bases followed by
+// hl - hlen backward steps -- the (k, l) the reference reaches after those steps -- as k | count << 40, 0 = absent,
+// count 0xFFFFFF = "too long for 24 bits: take the reference's path"
+__device__ __forceinline__ uint64_t lcl_entry(const LrmIndexView &ix, int hl, uint64_t code) {
     const int ext = hl - ix.hlen;
-    if (code >= (1ull << (2 * hl))) return;
     uint64_t k, l;
     lc_lookup(ix, code >> (2 * ext), k, l);
-    uint64_t e = 0;
-    if (!(k == 0 && l == 0)) {
-        for (int i = ext - 1; i >= 0 && k <= l; --i) {
-            const uint32_t c = (uint32_t) (code >> (2 * i)) & 3u;
-            uint64_t ra, rb;
-            occ_lf2(ix, c, k - 1, l, ra, rb);
-            k = ra + 1;
-            l = rb;
-        }
-        if (k <= l) {
-            const uint64_t cnt = l - k + 1;
-            e = cnt >= 0xFFFFFFull ? (0xFFFFFFull << 40) : (k | (cnt << 40));
-        }
+    if (k == 0 && l == 0) return 0;
+    for (int i = ext - 1; i >= 0 && k <= l; --i) {
+        const uint32_t c = (uint32_t) (code >> (2 * i)) & 3u;
+        uint64_t ra, rb;
+        occ_lf2(ix, c, k - 1, l, ra, rb);
+        k = ra + 1;
+        l = rb;
     }
-    out[code] = e;
+    if (k > l) return 0;
+    const uint64_t cnt = l - k + 1;
+    return cnt >= 0xFFFFFFull ? (0xFFFFFFull << 40) : (k | (cnt << 40));
 }
 
-// LRM_LC_LONG: 0 = off, 13..17 = that k-mer length, unset = automatic:
-//   17 (128 GiB) on GRCh38-scale texts (>= 2^31 rows) when that much HBM is free with 64 GiB to spare: a random 16-mer
-//      occurs in a 6.2 G-row text with p = 0.76, a 17-mer with 0.30, so most noisy seeds die in the lookup instead of
-//      one HBM-random step later: seed_search 40.6 -> 32.4 ms per Gbp on the GRCh38-sized text [r2];
-//   16 (32 GiB) once the occ table is far beyond the caches -- every backward step is then an HBM-random request:
-//      -32 % seed_search time on a chr1-sized text [r1];
-//   13 (512 MiB) on small texts: one step less per seed from a table that still mostly sits in the Infinity Cache:
-//      -2.7 % on the E. coli-sized text [r2] (14, 2 GiB, loses 2 %: its lookups go to HBM).
-// A table that does not fit falls back to the next smaller choice (17 -> 16 -> none): results never depend on it.
+// Long table, one lane per slot.  PLAIN layout: slot = hl-mer code.  PAIR-LINE layout (see seed_one): line S (an
+// (hl-1)-mer), slot a < 4: the entry of a.S; slot 4 + b: the entry of S.b -- every hl-mer is stored twice (once as a
+// left, once as a right extension of an (hl-1)-mer): 16 bytes per hl-mer.
+__global__ __launch_bounds__(256) void lcl_build_kernel(LrmIndexView ix, int hl, int pair, uint64_t *__restrict__ out,
+                                                        uint64_t slot0) {
+    const uint64_t slot = slot0 + (uint64_t) blockIdx.x * 256 + threadIdx.x;
+    uint64_t code = slot;
+    if (pair) {
+        const uint64_t S = slot >> 3;
+        if (S >= (1ull << (2 * (hl - 1)))) return;
+        const uint32_t w = (uint32_t) slot & 7u;
+        code = w < 4 ? ((S << 2) | w) : (S | ((uint64_t) (w - 4) << (2 * (hl - 1))));
+    } else if (code >= (1ull << (2 * hl))) {
+        return;
+    }
+    out[slot] = lcl_entry(ix, hl, code);
+}
+
+// The long seed table.  seed_search's time is its L2 misses divided by ~50 G random 64-byte lines per second, and
+// the first lookup of a seed is a miss whatever the text, so the table is (a) as long as HBM allows -- the longer the
+// k-mer, the more noisy seeds die in the lookup instead of one random step later -- and (b) in the pair-line layout,
+// where the lookups of two neighbouring read positions share a line.  Measured on 100 k x 10 kbp ONT reads, ms per Gbp
+// [r2]: E. coli-sized text plain 13-mers 24.5, pair-line 13 / 14 / 15 / 16-mers 19.2 / 18.5 / 17.6 / 15.6;
+// chr1-sized text plain 16 28.4, pair-line 16 20.3; GRCh38-sized text plain 16 40.6, plain 17 (128 GiB) 32.4,
+// pair-line 16 (64 GiB) 30.2.
+// Automatic choice: pair-line 16-mers (64 GiB) when that leaves 64 GiB of HBM free, else 15 (16 GiB, leaving 32),
+// 14 (4 GiB, leaving 8), 13 (1 GiB).  LRM_LC_LONG = 0 (off) | 13..17, LRM_LC_PAIR = 0 | 1 override.  A table that
+// cannot be allocated is skipped: results never depend on it.
 int lrm_lcl_prepare_index(lrm_index *idx) {
-    int hl = idx->view.length >= (1ull << 26) ? 16 : 13;
-    bool automatic = true;
-    if (idx->view.length >= (1ull << 31)) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= ((8ull << 34) + (64ull << 30))) hl = 17;
-    }
-    if (const char *e = getenv("LRM_LC_LONG")) { hl = atoi(e); automatic = false; }
-    if (hl <= idx->view.hlen || hl > 17 || idx->view.length < 2) return 0;
+    const uint64_t L = idx->view.length;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); free_b = 0; }
+    int hl = 13, pair = 1;
+    static const struct { int hl; uint64_t spare; } ladder[] = {{16, 64ull << 30}, {15, 32ull << 30}, {14, 8ull << 30}};
+    for (const auto &c : ladder)
+        if ((uint64_t) free_b >= (16ull << (2 * c.hl)) + c.spare) { hl = c.hl; break; }
+    if (const char *e = getenv("LRM_LC_LONG")) hl = atoi(e);
+    if (const char *e = getenv("LRM_LC_PAIR")) pair = atoi(e) != 0;
+    if (hl <= idx->view.hlen || hl > 17 || L < 2) return 0;
     uint64_t *d = nullptr;
-    uint64_t entries = 1ull << (2 * hl);
-    while (hipMalloc(&d, entries * 8) != hipSuccess) {               // no room: a smaller table, or the reference's table alone
-        (void) hipGetLastError();
-        d = nullptr;
-        if (!(automatic && hl == 17)) return 0;
-        hl = 16;
-        entries = 1ull << (2 * hl);
-    }
-    const uint64_t blocks = entries / 256, chunk = 1ull << 22;         // 2^30 threads per launch (grid limit 2^32)
-    for (uint64_t b0 = 0; b0 < blocks; b0 += chunk) {
+    const uint64_t slots = (pair ? 2ull : 1ull) << (2 * hl);
+    if (hipMalloc(&d, slots * 8) != hipSuccess) { (void) hipGetLastError(); return 0; }     // no room: the reference's table alone
+    const uint64_t chunk = 1ull << 22;                                // 2^30 threads per launch (grid limit 2^32)
+    for (uint64_t b0 = 0, blocks = slots / 256; b0 < blocks; b0 += chunk) {
         const uint64_t nb = blocks - b0 < chunk ? blocks - b0 : chunk;
-        hipLaunchKernelGGL(lcl_build_kernel, dim3((uint32_t) nb), dim3(256), 0, 0, idx->view, hl, d, b0 * 256);
+        hipLaunchKernelGGL(lcl_build_kernel, dim3((uint32_t) nb), dim3(256), 0, 0, idx->view, hl, pair, d, b0 * 256);
     }
     if (hipDeviceSynchronize() != hipSuccess) { (void) hipFree(d); lrm_set_error("long lc table build failed"); return -1; }
     idx->d_lcl = d;
     idx->view.lcl = d;
     idx->view.hl = hl;
+    idx->view.lcl_pair = pair;
     return 0;
 }
 
@@ -320,7 +342,7 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
             win = read_window(words, j);
         }
         uint64_t k, l;
-        const uint64_t rr = seed_one(ix, win, seed_len, k, l);
+        const uint64_t rr = seed_one(ix, win, seed_len, j, k, l);
         if (rr > 0 && rr < (uint64_t) thres) {
             const uint32_t slot = atomicAdd(&s_cnt[ph], 1u);
             atomicAdd(&s_hits[ph], (uint32_t) rr);
@@ -363,7 +385,7 @@ __global__ __launch_bounds__(256) void seed_search_debug_kernel(LrmIndexView ix,
     if (j >= jl) { j_out[o] = -1; return; }
     uint64_t win = read_window(words, (uint32_t) j);
     uint64_t k, l;
-    uint64_t rr = seed_one(ix, win, seed_len, k, l);
+    uint64_t rr = seed_one(ix, win, seed_len, (uint32_t) j, k, l);
     j_out[o] = (int32_t) j; rr_out[o] = rr; k_out[o] = k; l_out[o] = l;
 }
 

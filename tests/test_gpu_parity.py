@@ -122,20 +122,23 @@ def test_gact_rejects_unsupported_params(gpu):
         assert rc < 0 and b"unsupported GACT" in capi.lib.lrm_last_error()
 
 
-@pytest.mark.parametrize("long_table", ["0", "auto", "16"])
+@pytest.mark.parametrize("long_table", ["0", "auto", "16", "13-plain", "14"])
 @pytest.mark.parametrize("name", ["clean-1k", "ont-2k", "pacbio-3k-h12", "ragged", "seed12", "seed32",
                                   "seed-below-hlen", "repeats-ties"])
 def test_seed_search_per_seed(dev_indexes, gpu, monkeypatch, name, long_table):
     """K1 alone: (j, rr, k, l) of every seed of a read.  With LRM_LC_LONG=0 (the reference's table only) also the
     k > l pairs of failed searches are the reference's (fmidx.c:310-312); through the long seed table (automatic:
-    14-mers here; 16-mers on large texts) a seed that dies inside its last 14/16 bases reports k = l = 0 -- rr = 0
-    either way, and the reference never reads k, l of such a seed (alnmain.c:357-366)."""
-    if long_table == "16" and name not in ("ont-2k", "seed32"):
-        pytest.skip("the 32 GiB table is built for two scenarios only")
+    pair-line 16-mers when 128 GiB of HBM are free, shorter k-mers otherwise; "13-plain": the plain layout) a seed that
+    dies inside its last hl bases reports k = l = 0 -- rr = 0 either way, and the reference never reads k, l of such
+    a seed (alnmain.c:357-366)."""
+    if long_table in ("16", "13-plain", "14") and name not in ("ont-2k", "seed32", "ragged"):
+        pytest.skip("explicit table variants are built for three scenarios only")
     sc, di, oi = dev_indexes(name)
     own = None
     if long_table != "auto":
-        monkeypatch.setenv("LRM_LC_LONG", long_table)
+        monkeypatch.setenv("LRM_LC_LONG", long_table.split("-")[0])
+        if long_table.endswith("-plain"):
+            monkeypatch.setenv("LRM_LC_PAIR", "0")
         own = di = index.DeviceIndex.upload(sc["hi"], gpu)
     s = sc["seed_len"]
     for i in range(0, len(sc["lens"]), 5):
