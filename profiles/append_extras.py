@@ -13,7 +13,7 @@ ix, iso, pc, rf, cpu = d["index"], d["isolated"], d["pcie_inclusive"], d["roofli
 out = ["", "## GRCh38-sized text on one GPU (`bench_grch38_100k_x_10kbp.json`, `.log`)", "",
        "`python bench.py --ref-len 3099750718 --steps %d --warmup %d --cpu-seconds 8`: synthetic 3,099,750,718 bp reference "
        "(no FASTA on the box), L = %d rows; index built on the box's %d-CPU share in %.1f s (peak RSS %.1f GB), %.1f GiB "
-       "image packed + uploaded in %.1f s, 128 GiB long seed table (17-mers) derived on the device."
+       "image packed + uploaded in %.1f s, 64 GiB long seed table (pair-line 16-mers) derived on the device."
        % (d["steps"], d["warmup"], ix["rows"], ix["host_cpus"], ix["build_s"], ix["peak_rss_gb"], ix["image_bytes"] / 2**30,
           ix["pack_upload_s"]), "", "| | |", "|---|---|",
        "| `value` (HBM-resident, 3 streams) | **%.2f Gbp/s**, %.1f ms per 1-Gbp step |" % (d["value"], d["ms_per_step"]),
@@ -37,7 +37,7 @@ for f, what in (("bench_ecoli_131072_reads.json", "E. coli-sized text, 131,072 x
                 % (f, what, e["value"], e["isolated"]["value"], e["pcie_inclusive"]["pinned"]["value"], e["pcie_inclusive"]["pageable"]["value"],
                    e["isolated"]["roofline_gact"]["gcups"] / 1e3)]
 out += ["", "`pmc_grch38_seed_vote.json`: FETCH_SIZE and TCC_HIT/MISS of `seed_search` and `vote` on the GRCh38-sized workload (own `--pmc` passes): "
-        "seed_search fetches 95 GB per launch (1.52 G L2 misses x 64 B) in 32.2 ms with the 17-mer table, 128 GB (2.04 G misses) in 41.7 ms with the 16-mer table: 47-49 G random 64-byte lines per second either way."]
+        "with the PLAIN tables that preceded the pair-line layout: seed_search fetches 95 GB per launch (1.52 G L2 misses x 64 B) in 32.2 ms with the 17-mer table, 128 GB (2.04 G misses) in 41.7 ms with the 16-mer table: 47-49 G random 64-byte lines per second either way."]
 out += ["", "`large_test.log`: `tests/test_gpu_large.py` (4.4 G rows: loci, rows and SA values beyond 2^32 end to end against the oracle).",
         "", "`probes/`: raw outputs of the tuning probes behind the \"measured and rejected\" notes of `DESIGN.md` (its README lists them)."]
 with open(os.path.join(dst, "README.md"), "a") as f:
