@@ -200,6 +200,9 @@ void lrm_set_error(const char *fmt, ...);
 // (affinity mask, cgroup CPU quota) -- a GPU box hands a job 16 of its 256 hardware threads, and a team of 256 on a
 // quota of 16 is throttled to a crawl.  OMP_NUM_THREADS still lowers it.
 int lrm_host_threads(void);
+// Cap on the long seed table's k-mer length for index uploads issued by THIS thread (0 = none).  The 64 GiB 16-mer
+// table costs 0.7-2 s at upload and repays it after a few hundred Gbp of reads; lrm_accaln caps it for small inputs.
+extern thread_local int lrm_lcl_max_hl;
 int lrm_require_device(int device);
 int lrm_workspace_create_parts(lrm_workspace **out, lrm_index *idx, uint64_t n_max, uint32_t max_len, uint32_t seed_len,
                                uint32_t thres, int parts);

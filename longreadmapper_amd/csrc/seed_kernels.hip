@@ -217,7 +217,11 @@ __global__ __launch_bounds__(256) void lcl_build_kernel(LrmIndexView ix, int hl,
 // pair-line 16 (64 GiB) 30.2.
 // Automatic choice: pair-line 16-mers (64 GiB) when that leaves 64 GiB of HBM free, else 15 (16 GiB, leaving 32),
 // 14 (4 GiB, leaving 8), 13 (1 GiB).  LRM_LC_LONG = 0 (off) | 13..17, LRM_LC_PAIR = 0 | 1 override.  A table that
-// cannot be allocated is skipped: results never depend on it.
+// cannot be allocated is skipped: results never depend on it.  Cost at upload [r2]: 16 GiB and below ~10 ms, the 64 GiB
+// table 0.65 s (2 s when the memory was freed a moment ago) -- repaid after a few hundred Gbp of reads, so callers that
+// know their run is short cap the length (lrm_lcl_max_hl; lrm_accaln does it from the size of the reads file).
+thread_local int lrm_lcl_max_hl = 0;
+
 int lrm_lcl_prepare_index(lrm_index *idx) {
     const uint64_t L = idx->view.length;
     size_t free_b = 0, total_b = 0;
@@ -226,6 +230,7 @@ int lrm_lcl_prepare_index(lrm_index *idx) {
     static const struct { int hl; uint64_t spare; } ladder[] = {{16, 64ull << 30}, {15, 32ull << 30}, {14, 8ull << 30}};
     for (const auto &c : ladder)
         if ((uint64_t) free_b >= (16ull << (2 * c.hl)) + c.spare) { hl = c.hl; break; }
+    if (lrm_lcl_max_hl >= 13 && hl > lrm_lcl_max_hl) hl = lrm_lcl_max_hl;       // the caller expects a short run
     if (const char *e = getenv("LRM_LC_LONG")) hl = atoi(e);
     if (const char *e = getenv("LRM_LC_PAIR")) pair = atoi(e) != 0;
     if (hl <= idx->view.hlen || hl > 17 || L < 2) return 0;
