@@ -374,12 +374,15 @@ def main():
             # integer VALU issue: one wave64 instruction per 4 cycles per SIMD, 1024 SIMDs, 2.4 GHz peak clock
             peak_ips = 1024 * 2.4e9 / 4
             r["valu_issue_frac"] = k["valu_wave_insts_per_launch"] / (k["avg_ms"] * 1e-3) / peak_ips
+        if r["traffic"]:
+            r["traffic_frac"] = r["traffic"] / (k["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS      # bytes really moved vs the HBM peak
         if name == "seed_search_kernel":
             r["note"] = ("`achieved` counts the REFERENCE LAYOUT's algorithmic bytes (SURVEY 8d: 16 B per lc lookup + 8 B and the "
                          "scanned bwt bytes per _occ_access, from the oracle's exact counters); the device answers several of "
                          "those accesses with one request to its long seed table, so the bytes it really moves (`traffic`) are "
-                         "fewer and `frac` can exceed 1 on large texts -- it is a rate of reference work against the HBM peak, "
-                         "not a claim of more than peak bandwidth")
+                         "fewer and `frac` can reach or exceed 1 -- it is a rate of reference work against the HBM peak, not a "
+                         "claim of more than peak bandwidth; `traffic_frac` is the same ratio for the bytes really moved "
+                         "(random 64-byte lines: the kernel's time is its L2 misses / ~50 G lines per second)")
         if name in ("gact_kernel", "gact_bs_kernel"):
             r["gcups"] = per_base["cells"] * bases * args.steps / (ktimes[name][0] * 1e-3) / 1e9
             r["note"] = ("integer DP (gact): bound by VALU issue, not by HBM or MFMA -- its HBM fraction is small by "
