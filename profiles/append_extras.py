@@ -37,7 +37,7 @@ for f, what in (("bench_ecoli_131072_reads.json", "E. coli-sized text, 131,072 x
                 % (f, what, e["value"], e["isolated"]["value"], e["pcie_inclusive"]["pinned"]["value"], e["pcie_inclusive"]["pageable"]["value"],
                    e["isolated"]["roofline_gact"]["gcups"] / 1e3)]
 out += ["", "`pmc_grch38_seed_vote.json`: FETCH_SIZE and TCC_HIT/MISS of `seed_search` and `vote` on the GRCh38-sized workload (own `--pmc` passes): "
-        "with the PLAIN tables that preceded the pair-line layout: seed_search fetches 95 GB per launch (1.52 G L2 misses x 64 B) in 32.2 ms with the 17-mer table, 128 GB (2.04 G misses) in 41.7 ms with the 16-mer table: 47-49 G random 64-byte lines per second either way."]
+        "seed_search with the pair-line 16-mer table fetches 90 GB per launch (1.44 G L2 misses x 64 B) in 29.7 ms; with the PLAIN tables that preceded it it fetches 95 GB per launch (1.52 G L2 misses x 64 B) in 32.2 ms with the 17-mer table, 128 GB (2.04 G misses) in 41.7 ms with the 16-mer table: 47-49 G random 64-byte lines per second in all three."]
 out += ["", "`large_test.log`: `tests/test_gpu_large.py` (4.4 G rows: loci, rows and SA values beyond 2^32 end to end against the oracle).",
         "", "`probes/`: raw outputs of the tuning probes behind the \"measured and rejected\" notes of `DESIGN.md` (its README lists them)."]
 with open(os.path.join(dst, "README.md"), "a") as f:
