@@ -16,6 +16,10 @@
  *   PART 2 locus resolve + rev-comp + extension,                lrm_extend_batch
  *     alnmain.c:408-451, cigar_align mutils.h:57-58
  *   PART 1 + PART 2 in one device pass (one upload per batch)   lrm_map_batch
+ *   the batch loop with its planned copy clauses,                lrm_map_batch_submit / lrm_map_batch_wait
+ *     alnmain.c:302-330, 420-424 (batches overlap on the device)
+ *   params (run-time options), alnmain.h:10-13,                  lrm_index_options / lrm_map_options
+ *     alnmain.c:574-588
  *   PART 3 result flags, alnmain.c:458-477                      lrm_result_flags
  *   context_destroy(), accaln.c:7-43                            lrm_index_free
  *   host batch loop over devices, alnmain.c:302-330             lrm_index_upload_multi (+ the same batch calls)
@@ -41,7 +45,7 @@
 extern "C" {
 #endif
 
-#define LRM_ABI_VERSION 2
+#define LRM_ABI_VERSION 3
 
 /* histo/histo.h:21-23 `entry` */
 typedef struct lrm_entry { uint64_t key, val, bucket; } lrm_entry;
@@ -85,6 +89,51 @@ typedef struct lrm_gact_params { int T, O, W; } lrm_gact_params;
 #define LRM_GACT_W_DEFAULT 128
 
 typedef struct lrm_index lrm_index;       /* opaque: device-resident index */
+
+/* ---------------------------------------------------------------------------
+ * Run-time options (the reference's run-time surface is `params`, alnmain.h:10-13, filled from argv at
+ * alnmain.c:574-588; what is a choice of THIS implementation lives in the two structs below).
+ * Initialise with lrm_*_options_init (sets struct_size and the automatic choices), change fields, pass by pointer;
+ * NULL means "all automatic".  LRM_* environment variables remain as OVERRIDES for tuning sessions only: they are
+ * read once, when a handle is created, never per call.
+ * ------------------------------------------------------------------------- */
+typedef struct lrm_index_options {
+    uint32_t struct_size;      /* sizeof(lrm_index_options) of the caller's header */
+    int32_t sa_sampled;        /* 0 / 1: the full suffix array (sa_access, fmidx.c:18-33); r = 2..64, a power of two: only
+                                  rows i*r stay on the device -- r = 4 is the reference's csa table, fmidx.c:153-163 -- and the
+                                  kernels locate the other rows by LF steps (csa_access, fmidx.c:315-331): GRCh38 49.6 -> 12.4 GB */
+    int32_t lc_long;           /* k-mer length of the long seed table derived on the device: -1 automatic (the longest that
+                                  leaves room in HBM), 0 none (lchash alone, lchash.c:89-104), 13..17 */
+    int32_t lc_long_max;       /* cap on the automatic choice (0: none): the 64 GiB 16-mer table costs 0.7-2 s at upload, a
+                                  caller that knows its run is short says 15 */
+    int32_t lc_pair;           /* layout of the long table: -1 automatic (pair-line), 0 plain, 1 pair-line */
+    uint32_t lcx_threshold;    /* 0: default (2^24 - 1); lchash intervals of at least this many rows go through the side
+                                  table (tests) */
+    uint32_t reserved[10];
+} lrm_index_options;
+void lrm_index_options_init(lrm_index_options *o);
+
+typedef struct lrm_map_options {
+    uint32_t struct_size;      /* sizeof(lrm_map_options) of the caller's header */
+    int32_t dense_results;     /* 0: cig_out[i].cigar = store_mem + i*store_stride (alnmain.c:322-325).
+                                  1: DENSE -- cig_out[i].cigar = store_mem + off[i], the used op bytes of consecutive reads
+                                  packed back to back (16-byte aligned) inside the region of store_mem their rows would
+                                  occupy.  The convention of mutils.c:97-103 is kept (caller-owned buffer, callee-set
+                                  pointer); with store_mem pinned the device image of the op bytes is DMA'd straight into
+                                  it and the library spends no host CPU on the results.  Needs store_stride % 16 == 0. */
+    int32_t gact_impl;         /* extension kernel: 0 automatic, 1 one read per wavefront, 3 two reads per wavefront,
+                                  4 bit-sliced lane per read whenever it applies */
+    int32_t seed_rounds;       /* 0 automatic (phase 0 first unless the previous batch decided < 2 % there), 1, 2 */
+    int32_t direct_rows;       /* rows that must land in strided caller rows (the reverse-complemented reads, alnmain.c:437;
+                                  the op bytes when dense_results == 0), for PINNED caller buffers: -1 automatic, 1 the
+                                  device writes them into the caller's memory itself, 0 dense DMA + host scatter */
+    uint32_t slice_reads;      /* host pipeline shape, 0 = automatic: reads per device pass, */
+    uint32_t sub_batches;      /*   seed sub-batches per pass, */
+    uint32_t group_subs;       /*   sub-batches per extension group */
+    uint32_t bs_waves;         /* tests: cap on the resident wavefronts of the bit-sliced kernel (forces lane refills) */
+    uint32_t reserved[10];
+} lrm_map_options;
+void lrm_map_options_init(lrm_map_options *o);
 
 const char *lrm_last_error(void);
 int lrm_abi_version(void);
@@ -130,6 +179,25 @@ int lrm_index_upload_multi(lrm_index **out, const lrm_dna_fmi *fmi, const lrm_lc
 int lrm_index_replicas(const lrm_index *idx);
 lrm_index *lrm_index_replica(lrm_index *idx, int r);     /* borrowed; replica 0 is the handle itself */
 
+/* The same entry points with options (NULL = automatic).  lrm_index_upload_opt covers one device (ngpus == 1,
+ * devices[0]; devices == NULL means device 0..ngpus-1) and the multi-GPU group. */
+uint64_t lrm_index_blob_bytes_opt(uint64_t length, int hlen, int mta_len, const lrm_index_options *opt);
+int lrm_index_pack_blob_opt(const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa, const char *content,
+                            uint64_t con_len, const lrm_mta_entry *mta, int mta_len, void *blob, uint64_t blob_bytes,
+                            const lrm_index_options *opt);
+int lrm_index_pack_device_opt(const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa, const char *content,
+                              uint64_t con_len, const lrm_mta_entry *mta, int mta_len, void *d_blob, uint64_t blob_bytes,
+                              int device, const lrm_index_options *opt);
+int lrm_index_upload_opt(lrm_index **out, const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
+                         const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len,
+                         const int *devices, int ngpus, const lrm_index_options *opt);
+int lrm_index_adopt_device_opt(lrm_index **out, void *d_blob, uint64_t blob_bytes, int device, const lrm_index_options *opt);
+int lrm_index_upload_blob_opt(lrm_index **out, const void *blob, uint64_t blob_bytes, int device, const lrm_index_options *opt);
+
+/* Default options of the batch calls on this handle (every replica of a group): lrm_seed_batch, lrm_extend_batch,
+ * lrm_map_batch and the *_dev calls use them; lrm_map_batch_submit takes its own.  NULL restores the automatic choices. */
+int lrm_index_set_map_options(lrm_index *idx, const lrm_map_options *opt);
+
 /* Adopt a blob that already sits in device memory (e.g. the destination of an
  * RCCL broadcast).  The blob is borrowed: it must outlive the handle. */
 int lrm_index_adopt_device(lrm_index **out, void *d_blob, uint64_t blob_bytes, int device);
@@ -165,6 +233,20 @@ int lrm_map_batch(lrm_index *idx, char *reads_buf, uint64_t stride, const uint32
                   lrm_params p, lrm_gact_params gp, lrm_entry *best_out, lrm_cigar *cig_out,
                   uint8_t *store_mem, uint64_t store_stride, int *score_out, lrm_seq_meta *meta_out,
                   int *meta_r_out);
+
+/* The same, asynchronous: lrm_map_batch_submit queues the batch and returns; lrm_map_batch_wait blocks until its
+ * results are in the caller's arrays, returns the batch's status and frees the ticket.  Up to TWO batches per device
+ * are in flight on the device at once -- the upload and the seeds of batch k+1 run under the extension tail and the
+ * result download of batch k, which is the chain that bounds a single call (alnmain.c:302-330 with the copy clauses
+ * planned at :420-424) -- further submissions queue.  Every argument array must stay valid, and untouched by the
+ * caller, until the wait returns; batches complete in submission order.  lrm_map_batch == submit + wait.
+ * opt == NULL: the handle's default options. */
+typedef struct lrm_ticket lrm_ticket;
+int lrm_map_batch_submit(lrm_index *idx, char *reads_buf, uint64_t stride, const uint32_t *lens, uint64_t n,
+                         lrm_params p, lrm_gact_params gp, lrm_entry *best_out, lrm_cigar *cig_out,
+                         uint8_t *store_mem, uint64_t store_stride, int *score_out, lrm_seq_meta *meta_out,
+                         int *meta_r_out, const lrm_map_options *opt, lrm_ticket **ticket_out);
+int lrm_map_batch_wait(lrm_ticket *ticket);
 
 /* Pinned host memory for the batch buffers (reads_buf, store_mem): the DMA engines then read / write the
  * caller's memory directly; pageable buffers work too and are staged through pinned chunks.
@@ -236,6 +318,14 @@ int lrm_debug_seed_search(lrm_index *idx, const char *read, uint32_t len, uint32
                           uint32_t thres, int32_t *j_out, uint64_t *rr_out, uint64_t *k_out,
                           uint64_t *l_out, uint64_t cap, uint64_t *n_out);
 
+/* Test-only: force the multi-pass vote tier of this handle's batches into overflow (a pass limit above the table size
+ * and a small table); 0, 0 restores the defaults. */
+int lrm_debug_set_vote_limits(lrm_index *idx, uint32_t t3_limit, uint32_t t3_slots);
+
+/* Tuning sessions only (tools/): re-read the LRM_* overrides for the batch calls of this handle (normally they are
+ * read once, when the handle is created). */
+int lrm_debug_reload_env(lrm_index *idx);
+
 /* RCCL self-test (tests only): dlopen + ncclCommInitAll + a 1-rank grouped ncclBroadcast of `bytes` bytes on
  * `device`.  0 ok, 1 librccl not loadable (lrm_index_upload_multi then uses hipMemcpyPeer), <0 error. */
 int lrm_debug_rccl_selftest(int device, uint64_t bytes);
@@ -243,6 +333,9 @@ int lrm_debug_rccl_selftest(int device, uint64_t bytes);
 /* Direct kernel tap (tests only): simple_gact on one (q, d) pair. */
 int lrm_debug_gact(const char *q, int n, const char *d, int m, lrm_gact_params gp,
                    uint8_t *ops, int *n_ops, int *score, int device);
+/* ... with the kernel chosen by the caller (lrm_map_options.gact_impl values) */
+int lrm_debug_gact_impl(const char *q, int n, const char *d, int m, lrm_gact_params gp, int impl,
+                        uint8_t *ops, int *n_ops, int *score, int device);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,19 @@ class GactParams(C.Structure):
     _fields_ = [("T", C.c_int), ("O", C.c_int), ("W", C.c_int)]
 
 
+class IndexOptions(C.Structure):       # lrm_index_options
+    _fields_ = [("struct_size", C.c_uint32), ("sa_sampled", C.c_int32), ("lc_long", C.c_int32),
+                ("lc_long_max", C.c_int32), ("lc_pair", C.c_int32), ("lcx_threshold", C.c_uint32),
+                ("reserved", C.c_uint32 * 10)]
+
+
+class MapOptions(C.Structure):         # lrm_map_options
+    _fields_ = [("struct_size", C.c_uint32), ("dense_results", C.c_int32), ("gact_impl", C.c_int32),
+                ("seed_rounds", C.c_int32), ("direct_rows", C.c_int32), ("slice_reads", C.c_uint32),
+                ("sub_batches", C.c_uint32), ("group_subs", C.c_uint32), ("bs_waves", C.c_uint32),
+                ("reserved", C.c_uint32 * 10)]
+
+
 class Stats(C.Structure):
     _fields_ = [("vote_tier2_items", C.c_uint64), ("vote_tier3_items", C.c_uint64),
                 ("reads_decided_phase0", C.c_uint64), ("gact_tiles", C.c_uint64)]
@@ -87,6 +100,31 @@ SYMBOLS = {
                                    C.POINTER(SaMem), C.c_void_p, C.c_uint64, C.POINTER(MtaEntry), C.c_int, C.c_int]),
     "lrm_index_pack_device": (C.c_int, [C.POINTER(DnaFmi), C.POINTER(LcHash), C.POINTER(SaMem), C.c_void_p,
                                         C.c_uint64, C.POINTER(MtaEntry), C.c_int, C.c_void_p, C.c_uint64, C.c_int]),
+    "lrm_index_options_init": (None, [C.POINTER(IndexOptions)]),
+    "lrm_map_options_init": (None, [C.POINTER(MapOptions)]),
+    "lrm_index_blob_bytes_opt": (C.c_uint64, [C.c_uint64, C.c_int, C.c_int, C.POINTER(IndexOptions)]),
+    "lrm_index_pack_blob_opt": (C.c_int, [C.POINTER(DnaFmi), C.POINTER(LcHash), C.POINTER(SaMem), C.c_void_p,
+                                          C.c_uint64, C.POINTER(MtaEntry), C.c_int, C.c_void_p, C.c_uint64,
+                                          C.POINTER(IndexOptions)]),
+    "lrm_index_pack_device_opt": (C.c_int, [C.POINTER(DnaFmi), C.POINTER(LcHash), C.POINTER(SaMem), C.c_void_p,
+                                            C.c_uint64, C.POINTER(MtaEntry), C.c_int, C.c_void_p, C.c_uint64, C.c_int,
+                                            C.POINTER(IndexOptions)]),
+    "lrm_index_upload_opt": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(DnaFmi), C.POINTER(LcHash),
+                                       C.POINTER(SaMem), C.c_void_p, C.c_uint64, C.POINTER(MtaEntry), C.c_int,
+                                       C.POINTER(C.c_int), C.c_int, C.POINTER(IndexOptions)]),
+    "lrm_index_adopt_device_opt": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_int,
+                                             C.POINTER(IndexOptions)]),
+    "lrm_index_upload_blob_opt": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_int,
+                                            C.POINTER(IndexOptions)]),
+    "lrm_index_set_map_options": (C.c_int, [C.c_void_p, C.POINTER(MapOptions)]),
+    "lrm_map_batch_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, Params, GactParams,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.POINTER(MapOptions), C.POINTER(C.c_void_p)]),
+    "lrm_map_batch_wait": (C.c_int, [C.c_void_p]),
+    "lrm_debug_reload_env": (C.c_int, [C.c_void_p]),
+    "lrm_debug_set_vote_limits": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "lrm_debug_gact_impl": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, GactParams, C.c_int, C.c_void_p,
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
     "lrm_index_adopt_device": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_int]),
     "lrm_index_upload_blob": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_int]),
     "lrm_index_free": (None, [C.c_void_p]),
@@ -179,6 +217,26 @@ def _load():
 
 
 lib = _load()
+
+
+def index_options(**kw):
+    """lrm_index_options with the automatic choices, then the given fields (None = automatic)."""
+    o = IndexOptions()
+    lib.lrm_index_options_init(C.byref(o))
+    for k, v in kw.items():
+        if v is not None:
+            setattr(o, k, v)          # AttributeError for a field the struct does not have
+    return o
+
+
+def map_options(**kw):
+    o = MapOptions()
+    lib.lrm_map_options_init(C.byref(o))
+    for k, v in kw.items():
+        if v is not None:
+            getattr(o, k)             # AttributeError for a field the struct does not have
+            setattr(o, k, v)
+    return o
 
 
 class LrmError(RuntimeError):

@@ -584,9 +584,7 @@ __global__ __launch_bounds__(256) void bs_expand_kernel(const uint64_t *__restri
 
 uint64_t lrm_bs_planar_words(uint64_t len) { return 2 * ((len + 63) / 64) + 2 * (uint64_t) BS_PADW; }
 
-bool lrm_bs_wanted(lrm_gact_params gp, uint64_t n) {
-    const char *e = getenv("LRM_GACT_IMPL");
-    const int impl = e ? atoi(e) : 0;
+bool lrm_bs_wanted(lrm_gact_params gp, uint64_t n, int impl) {
     return gp.W <= 128 && (impl == 4 || (impl == 0 && n >= LRM_BS_MIN_READS));
 }
 
@@ -659,14 +657,11 @@ uint64_t lrm_bs_ckpt_words(uint64_t n) {                     // T - O <= 512: at
 
 int lrm_bs_launch(const LrmBsArgs *bs, const uint32_t *d_lens, const lrm_seq_meta *d_meta, const int32_t *d_meta_r,
                   const uint32_t *d_tlens, uint64_t n, int T, int O, int W, uint8_t *d_store, uint64_t store_stride,
-                  int32_t *d_n_ops, int32_t *d_score, LrmDevCounters *counters, void *stream_) {
+                  int32_t *d_n_ops, int32_t *d_score, LrmDevCounters *counters, uint32_t max_waves, void *stream_) {
     hipStream_t stream = (hipStream_t) stream_;
     uint64_t blocks = (n + 63) / 64;
     if (blocks > LRM_BS_MAX_WAVES) blocks = LRM_BS_MAX_WAVES;              // resident wavefronts; lanes refill from the queue
-    if (const char *e = getenv("LRM_BS_WAVES")) {                          // test knob: a small grid forces refills
-        const uint64_t w = (uint64_t) atoll(e);
-        if (w >= 1 && w < blocks) blocks = w;
-    }
+    if (max_waves >= 1 && max_waves < blocks) blocks = max_waves;          // (tests: a small grid forces refills)
     HIPCHK(hipMemsetAsync(&counters->reserved[0], 0, sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(gact_bs_kernel, dim3((uint32_t) blocks), dim3(64), 0, stream, bs->qpl, bs->wpr, d_lens, d_meta,
                        d_meta_r, bs->cpl + BS_PADW, d_tlens, bs->flags, n, T, O, W, bs->ckpt, bs->codes, bs->cw,

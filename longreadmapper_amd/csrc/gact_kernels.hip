@@ -690,22 +690,20 @@ static int launch_one_per_wave(lrm_gact_params gp, uint64_t n, hipStream_t strea
 static int gact_launch(lrm_gact_params gp, uint64_t n, hipStream_t stream, const char *reads, uint64_t stride,
                        const uint32_t *lens, const lrm_seq_meta *meta, const int32_t *meta_r, const char *content,
                        const uint32_t *tlens, uint8_t *store, uint64_t store_stride, int32_t *n_ops, int32_t *score,
-                       LrmDevCounters *counters, const LrmBsArgs *bs) {
+                       LrmDevCounters *counters, const LrmBsArgs *bs, int impl, uint32_t bs_waves) {
     if (gp.W > 128)
         return launch_one_per_wave(gp, n, stream, reads, stride, lens, meta, meta_r, content, tlens, store, store_stride,
                                    n_ops, score, counters, nullptr);
-    // LRM_GACT_IMPL (read at every call so that tests can switch): 0 = automatic, 1 = one read per wavefront,
-    // 3 = packed two reads per wavefront, 4 = bit-sliced lane per read whenever it applies (W <= 128, pure ACGT
-    // text, 4-byte aligned CIGAR store; otherwise as 0)
-    int impl = 0;
-    { const char *e = getenv("LRM_GACT_IMPL"); impl = e ? atoi(e) : 0; }
+    // impl (lrm_map_options.gact_impl): 0 = automatic, 1 = one read per wavefront, 3 = packed two reads per wavefront,
+    // 4 = bit-sliced lane per read whenever it applies (W <= 128, pure ACGT text, 4-byte aligned CIGAR store;
+    // otherwise as 0)
     const int nblk = ((2 * (gp.T - gp.O) - 1) >> 4) + 1;
     // Bit-sliced kernel: a wavefront carries 64 reads, so it needs a large batch to fill the chip
     // (below ~16 k reads the two-reads-per-wavefront kernel finishes first).
     const bool bs_ok = bs && bs->cpl && gp.W <= 128 && (((uintptr_t) store | (uintptr_t) store_stride) & 3u) == 0;
     if (bs_ok && (impl == 4 || (impl == 0 && n >= LRM_BS_MIN_READS))) {
         if (lrm_bs_launch(bs, lens, meta, meta_r, tlens, n, gp.T, gp.O, gp.W, store, store_stride, n_ops, score, counters,
-                          stream)) return -1;
+                          bs_waves, stream)) return -1;
         // reads holding a byte other than ACGT (rare): one read per wavefront, flagged reads only
         return launch_one_per_wave(gp, n, stream, reads, stride, lens, meta, meta_r, content, tlens, store, store_stride,
                                    n_ops, score, counters, bs->flags);
@@ -733,7 +731,7 @@ int lrm_launch_extend(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint64_t
                       const uint32_t *d_lens, uint64_t n, uint32_t max_len,
                       const lrm_entry *d_best, lrm_gact_params gp, uint8_t *d_store,
                       uint64_t store_stride, int32_t *d_n_ops, int32_t *d_score,
-                      lrm_seq_meta *d_meta, int32_t *d_meta_r, void *stream_) {
+                      lrm_seq_meta *d_meta, int32_t *d_meta_r, const LrmMapTune &mt, void *stream_) {
     hipStream_t stream = (hipStream_t) stream_;
     if (n == 0) return 0;
     if (gp.T == 0 && gp.O == 0 && gp.W == 0) {
@@ -764,7 +762,7 @@ int lrm_launch_extend(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint64_t
         lrm_time_end(ws, stream);
     }
     LrmBsArgs bs = {};
-    const bool want_bs = lrm_bs_wanted(gp, n) && idx->d_cpl && idx->cpl_ok && ws->d_qpl && n <= ws->n_max &&
+    const bool want_bs = lrm_bs_wanted(gp, n, mt.gact_impl) && idx->d_cpl && idx->cpl_ok && ws->d_qpl && n <= ws->n_max &&
                          max_len <= ws->max_len;
     if (want_bs) {
         lrm_time_begin(ws, LRM_K_PACK_PLANAR, stream);
@@ -777,7 +775,7 @@ int lrm_launch_extend(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint64_t
     lrm_time_begin(ws, runs_bs ? LRM_K_GACT_BS : LRM_K_GACT, stream);
     if (gact_launch(gp, n, stream, d_reads, stride, d_lens, d_meta, d_meta_r, idx->view.content,
                     (const uint32_t *) nullptr, d_store, store_stride, d_n_ops, d_score, ws->d_counters,
-                    want_bs ? &bs : nullptr)) return -1;
+                    want_bs ? &bs : nullptr, mt.gact_impl, mt.bs_waves)) return -1;
     lrm_time_end(ws, stream);
     HIPCHK(hipGetLastError());
     return 0;
@@ -786,6 +784,15 @@ int lrm_launch_extend(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint64_t
 // direct kernel tap (tests only): simple_gact on one (q, d) pair, m may differ from n
 extern "C" int lrm_debug_gact(const char *q, int n, const char *d, int m, lrm_gact_params gp, uint8_t *ops,
                               int *n_ops, int *score, int device) {
+    LrmEnv env;                                  // a tap without a handle: LRM_GACT_IMPL as it stands now
+    lrm_env_snapshot(&env);
+    long long impl = 0;
+    (void) env.get("LRM_GACT_IMPL", &impl);
+    return lrm_debug_gact_impl(q, n, d, m, gp, (int) impl, ops, n_ops, score, device);
+}
+
+extern "C" int lrm_debug_gact_impl(const char *q, int n, const char *d, int m, lrm_gact_params gp, int impl, uint8_t *ops,
+                                   int *n_ops, int *score, int device) {
     if (!q || !d || !ops || !n_ops || !score || n < 0 || m < 0) { lrm_set_error("bad argument"); return -1; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -825,7 +832,7 @@ extern "C" int lrm_debug_gact(const char *q, int n, const char *d, int m, lrm_ga
     HIPCHK(hipMemcpy(dm, &hm, sizeof(hm), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dr, hr, 12, hipMemcpyHostToDevice));
     LrmBsArgs bs = {};
-    if (lrm_bs_wanted(gp, 1)) {
+    if (lrm_bs_wanted(gp, 1, impl)) {
         const uint64_t wq = lrm_bs_planar_words((uint64_t) n), wd = lrm_bs_planar_words((uint64_t) m);
         bs.cw = lrm_bs_code_words((uint32_t) (n > m ? n : m));
         if (bqpl.alloc(wq * 8 + 16) || bcpl.alloc(wd * 8 + 16) || bfl.alloc(16) || bcodes.alloc(bs.cw * 8 + 16) ||
@@ -838,7 +845,7 @@ extern "C" int lrm_debug_gact(const char *q, int n, const char *d, int m, lrm_ga
         bs.qpl = (uint64_t *) bqpl.p; bs.wpr = wq; bs.flags = dfl; bs.cpl = tf ? nullptr : (uint64_t *) bcpl.p;
         bs.codes = (uint64_t *) bcodes.p; bs.ckpt = (uint32_t *) bck.p; bs.ncodes = (int32_t *) (dfl + 2);
     }
-    if (gact_launch(gp, 1, 0, dq, 0, dl, dm, dr, dd, dl + 1, dops, 0, dr + 1, dr + 2, dc, bs.qpl ? &bs : nullptr)) return -1;
+    if (gact_launch(gp, 1, 0, dq, 0, dl, dm, dr, dd, dl + 1, dops, 0, dr + 1, dr + 2, dc, bs.qpl ? &bs : nullptr, impl, 0)) return -1;
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(hr, dr, 12, hipMemcpyDeviceToHost));

@@ -321,12 +321,13 @@ extern "C" int lrm_accaln(const char *genome, const char *reads_path, const char
     if (lrm_host_index_read(genome, &hi)) return -1;                       // init(), alnmain.c:179-256
     const double t_read_idx = now();
     lrm_index *gpu = nullptr;
+    lrm_index_options iopt;
+    lrm_index_options_init(&iopt);
     {   // a reads file below 64 GiB (some tens of Gbp) does not repay the 0.7-2 s the 64 GiB seed table costs at upload
         struct stat st;
-        if (stat(reads_path, &st) == 0 && (uint64_t) st.st_size < (64ull << 30)) lrm_lcl_max_hl = 15;
+        if (stat(reads_path, &st) == 0 && (uint64_t) st.st_size < (64ull << 30)) iopt.lc_long_max = 15;
     }
-    int rc = lrm_index_upload(&gpu, &hi.fmi, &hi.lch, &hi.sa, hi.content, hi.con_len, hi.mta, hi.mta_len, device);
-    lrm_lcl_max_hl = 0;
+    int rc = lrm_index_upload_opt(&gpu, &hi.fmi, &hi.lch, &hi.sa, hi.content, hi.con_len, hi.mta, hi.mta_len, &device, 1, &iopt);
     const double t_upload = now();
     FILE *out = nullptr;
     lrm_reader *rd = nullptr;

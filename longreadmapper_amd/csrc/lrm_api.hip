@@ -28,8 +28,10 @@ void lrm_set_error(const char *fmt, ...) {
 
 extern "C" const char *lrm_last_error(void) { return g_err; }
 int lrm_host_threads(void) {
-    static const int n = []() {
-        int m = omp_get_max_threads();
+    // the CPUs this process may use (affinity mask, cgroup quota) are read once; the caller's OpenMP thread limit is
+    // followed on every call (a host program may lower it between calls)
+    static const int cap = []() {
+        int m = 1 << 20;
         cpu_set_t set;
         if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c >= 1 && c < m) m = c; }
         long long quota = -1, period = 0;
@@ -46,7 +48,9 @@ int lrm_host_threads(void) {
         if (quota > 0 && period > 0) { const int c = (int) (quota / period); if (c >= 1 && c < m) m = c; }
         return m < 1 ? 1 : m;
     }();
-    return n;
+    const int m = omp_get_max_threads();
+    const int n = m < cap ? m : cap;
+    return n < 1 ? 1 : n;
 }
 
 extern "C" int lrm_abi_version(void) { return LRM_ABI_VERSION; }
@@ -60,14 +64,91 @@ extern "C" int lrm_device_count(void) {
 static inline uint64_t align256(uint64_t x) { return (x + 255ull) & ~255ull; }
 #define LRM_LCX_MAX 4096    // capacity of the long-interval side table
 
-// LRM_SA_SAMPLED=r (r a power of two, 2..64): keep only SA rows i*r in the image -- the reference's `csa`
-// table (fmidx.c:153-163, csa_ratio 4) -- and locate the other rows with <= r-1 LF steps on the device
-// (csa_access, fmidx.c:315-331).  1 / unset: the full SA (sa_access, fmidx.c:18-33).
-static int env_sa_ratio() {
-    const char *e = getenv("LRM_SA_SAMPLED");
-    if (!e) return 1;
-    const int r = atoi(e);
-    return (r >= 2 && r <= 64 && (r & (r - 1)) == 0) ? r : 1;
+// ------------------------------------------------------------------------------------------
+// options: the caller's structs, then the LRM_* environment overrides as they stood when the handle was created
+// ------------------------------------------------------------------------------------------
+static const char *const k_env_names[] = {
+    "LRM_SA_SAMPLED", "LRM_LC_LONG", "LRM_LC_PAIR", "LRM_LCX_THRESHOLD",                         // index
+    "LRM_GACT_IMPL", "LRM_SEED_ROUNDS", "LRM_HOST_DENSE", "LRM_HOST_DIRECT", "LRM_HOST_SLICE", "LRM_HOST_SUBS",
+    "LRM_HOST_GROUP", "LRM_BS_WAVES", "LRM_SS_ITEMS", "LRM_VOTE_VG", "LRM_VOTE_T1", "LRM_VOTE_U", "LRM_VOTE_LOAD",
+    "LRM_HOST_EXT_STREAMS", "LRM_HOST_SEED_STREAMS", "LRM_HOST_VERBOSE", "LRM_VOTE_SORT"};
+static_assert(sizeof(k_env_names) / sizeof(k_env_names[0]) <= LrmEnv::MAXV, "LrmEnv too small");
+
+void lrm_env_snapshot(LrmEnv *e) {
+    e->n = 0;
+    for (const char *name : k_env_names)
+        if (const char *v = getenv(name)) {
+            e->name[e->n] = name;
+            e->val[e->n] = *v ? strtoll(v, nullptr, 0) : 1;            // a variable set to the empty string counts as 1
+            e->n++;
+        }
+}
+bool LrmEnv::get(const char *key, long long *out) const {
+    for (int i = 0; i < n; ++i) if (strcmp(name[i], key) == 0) { *out = val[i]; return true; }
+    return false;
+}
+
+extern "C" void lrm_index_options_init(lrm_index_options *o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->struct_size = (uint32_t) sizeof(*o);
+    o->lc_long = -1;
+    o->lc_pair = -1;
+}
+extern "C" void lrm_map_options_init(lrm_map_options *o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->struct_size = (uint32_t) sizeof(*o);
+    o->direct_rows = -1;
+}
+
+static inline bool valid_sa_ratio(long long r) { return r >= 2 && r <= 64 && (r & (r - 1)) == 0; }
+
+// sa_sampled = r (a power of two, 2..64): keep only SA rows i*r in the image -- the reference's `csa` table
+// (fmidx.c:153-163, csa_ratio 4) -- and locate the other rows by LF steps on the device (csa_access,
+// fmidx.c:315-331: expected r steps per row, no fixed bound: the walk ends at a stored row or at the '$' row).
+void lrm_resolve_index_tune(const lrm_index_options *opt, const LrmEnv &env, LrmIndexTune *t) {
+    lrm_index_options o;
+    lrm_index_options_init(&o);
+    if (opt) memcpy(&o, opt, opt->struct_size && opt->struct_size < sizeof(o) ? opt->struct_size : sizeof(o));
+    t->sa_ratio = valid_sa_ratio(o.sa_sampled) ? o.sa_sampled : 1;
+    t->lc_long = o.lc_long; t->lc_long_max = o.lc_long_max; t->lc_pair = o.lc_pair;
+    t->lcx_threshold = o.lcx_threshold >= 1 && o.lcx_threshold <= 0xFFFFFFu ? o.lcx_threshold : 0xFFFFFFull;
+    long long v;
+    if (env.get("LRM_SA_SAMPLED", &v)) t->sa_ratio = valid_sa_ratio(v) ? (int) v : 1;
+    if (env.get("LRM_LC_LONG", &v)) t->lc_long = (int) v;
+    if (env.get("LRM_LC_PAIR", &v)) t->lc_pair = v != 0;
+    if (env.get("LRM_LCX_THRESHOLD", &v) && v >= 1 && v <= 0xFFFFFFll) t->lcx_threshold = (uint64_t) v;
+}
+
+void lrm_resolve_map_tune(const lrm_map_options *opt, const LrmEnv &env, LrmMapTune *t) {
+    lrm_map_options o;
+    lrm_map_options_init(&o);
+    if (opt) memcpy(&o, opt, opt->struct_size && opt->struct_size < sizeof(o) ? opt->struct_size : sizeof(o));
+    memset(t, 0, sizeof(*t));
+    t->dense = o.dense_results != 0;
+    t->gact_impl = o.gact_impl; t->seed_rounds = o.seed_rounds; t->direct_rows = o.direct_rows;
+    t->slice_reads = o.slice_reads; t->sub_batches = o.sub_batches; t->group_subs = o.group_subs; t->bs_waves = o.bs_waves;
+    // measured defaults of the kernel knobs (tools/seed_probe.py sweeps them through the environment)
+    t->ss_items = 2048; t->vote_vg = 16; t->vote_t1 = LRM_VOTE_T1_LIMIT; t->vote_u = 2; t->vote_load = 50;
+    t->ext_streams = 2; t->seed_streams = 2;
+    long long v;
+    if (env.get("LRM_GACT_IMPL", &v)) t->gact_impl = (int) v;
+    if (env.get("LRM_SEED_ROUNDS", &v)) t->seed_rounds = (int) v;
+    if (env.get("LRM_HOST_DENSE", &v)) t->dense = v != 0;
+    if (env.get("LRM_HOST_DIRECT", &v)) t->direct_rows = v != 0;
+    if (env.get("LRM_HOST_SLICE", &v) && v >= 1) t->slice_reads = (uint32_t) v;
+    if (env.get("LRM_HOST_SUBS", &v) && v >= 1) t->sub_batches = (uint32_t) v;
+    if (env.get("LRM_HOST_GROUP", &v) && v >= 1) t->group_subs = (uint32_t) v;
+    if (env.get("LRM_BS_WAVES", &v) && v >= 1) t->bs_waves = (uint32_t) v;
+    if (env.get("LRM_SS_ITEMS", &v) && (v == 1024 || v == 2048 || v == 4096)) t->ss_items = (uint32_t) v;
+    if (env.get("LRM_VOTE_VG", &v) && v >= 1 && v <= 64) t->vote_vg = (uint32_t) v;
+    if (env.get("LRM_VOTE_T1", &v) && v >= 0 && v <= LRM_VOTE_T1_LIMIT) t->vote_t1 = (uint32_t) v;
+    if (env.get("LRM_VOTE_U", &v)) t->vote_u = (uint32_t) v;
+    if (env.get("LRM_VOTE_LOAD", &v) && v >= 10 && v <= 95) t->vote_load = (uint32_t) v;
+    if (env.get("LRM_HOST_EXT_STREAMS", &v) && v >= 1 && v <= 4) t->ext_streams = (int) v;
+    if (env.get("LRM_HOST_SEED_STREAMS", &v) && v >= 1 && v <= 3) t->seed_streams = (int) v;
+    if (env.get("LRM_HOST_VERBOSE", &v)) t->verbose = v != 0;
 }
 
 static void blob_layout(uint64_t length, int hlen, int mta_len, int sa_ratio, LrmBlobHeader *h) {
@@ -92,10 +173,21 @@ static void blob_layout(uint64_t length, int hlen, int mta_len, int sa_ratio, Lr
     h->total_bytes = off;
 }
 
-extern "C" uint64_t lrm_index_blob_bytes(uint64_t length, int hlen, int mta_len) {
+static void tune_of(const lrm_index_options *opt, LrmIndexTune *t) {
+    LrmEnv env;
+    lrm_env_snapshot(&env);
+    lrm_resolve_index_tune(opt, env, t);
+}
+
+extern "C" uint64_t lrm_index_blob_bytes_opt(uint64_t length, int hlen, int mta_len, const lrm_index_options *opt) {
+    LrmIndexTune t;
+    tune_of(opt, &t);
     LrmBlobHeader h;
-    blob_layout(length, hlen, mta_len, env_sa_ratio(), &h);
+    blob_layout(length, hlen, mta_len, t.sa_ratio, &h);
     return h.total_bytes;
+}
+extern "C" uint64_t lrm_index_blob_bytes(uint64_t length, int hlen, int mta_len) {
+    return lrm_index_blob_bytes_opt(length, hlen, mta_len, nullptr);
 }
 
 static inline int code_of(char c) {
@@ -118,7 +210,9 @@ struct BlobPacker {
     std::vector<uint64_t> lcx;                           // side table, sorted {code, k, l}
 
     int init(const lrm_dna_fmi *fmi_, const lrm_lc_hash *lch_, const lrm_sa_mem *sa_, const char *content_,
-             uint64_t con_len, const lrm_mta_entry *mta_, int mta_len_) {
+             uint64_t con_len, const lrm_mta_entry *mta_, int mta_len_, const lrm_index_options *opt) {
+        LrmIndexTune tune;
+        tune_of(opt, &tune);
         fmi = fmi_; lch = lch_; sa = sa_; content = content_; mta = mta_; mta_len = mta_len_;
         if (!fmi || !lch || !sa || !content) { lrm_set_error("null argument"); return -1; }
         L = fmi->length;
@@ -128,7 +222,7 @@ struct BlobPacker {
         if (lch->hlen < 1 || lch->hlen > 15) { lrm_set_error("hlen %d outside [1,15] (lchash.c:75-77)", lch->hlen); return -1; }
         if (lch->len != 2ull << (2 * lch->hlen)) { lrm_set_error("lc table length %llu != 2*4^hlen", (unsigned long long) lch->len); return -1; }
         if (mta_len < 0 || (mta_len > 0 && !mta)) { lrm_set_error("bad mta"); return -1; }
-        blob_layout(L, lch->hlen, mta_len, env_sa_ratio(), &h);
+        blob_layout(L, lch->hlen, mta_len, tune.sa_ratio, &h);
         h.c4[0] = fmi->c[(unsigned char) 'A']; h.c4[1] = fmi->c[(unsigned char) 'C'];
         h.c4[2] = fmi->c[(unsigned char) 'G']; h.c4[3] = fmi->c[(unsigned char) 'T'];
 
@@ -161,8 +255,7 @@ struct BlobPacker {
         for (int x = 0; x < 4; ++x) total[x] = seg_cnt[nseg * 4 + x];
 
         // side table of the lc intervals that do not fit 24 bits of length
-        uint64_t long_thr = 0xFFFFFFull;           // testing knob: send shorter intervals through the side table too
-        if (const char *e = getenv("LRM_LCX_THRESHOLD")) { long_thr = strtoull(e, nullptr, 0); if (long_thr < 1 || long_thr > 0xFFFFFFull) long_thr = 0xFFFFFFull; }
+        const uint64_t long_thr = tune.lcx_threshold;           // (tests send shorter intervals through the side table too)
         lcx_thr = long_thr;
         std::vector<uint64_t> over;
         const uint64_t ne = h.lc_entries;
@@ -326,9 +419,14 @@ struct BlobPacker {
 extern "C" int lrm_index_pack_blob(const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
                                    const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len,
                                    void *blob, uint64_t blob_bytes) {
+    return lrm_index_pack_blob_opt(fmi, lch, sa, content, con_len, mta, mta_len, blob, blob_bytes, nullptr);
+}
+extern "C" int lrm_index_pack_blob_opt(const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
+                                       const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len,
+                                       void *blob, uint64_t blob_bytes, const lrm_index_options *opt) {
     if (!blob) { lrm_set_error("null argument"); return -1; }
     BlobPacker pk;
-    if (pk.init(fmi, lch, sa, content, con_len, mta, mta_len)) return -1;
+    if (pk.init(fmi, lch, sa, content, con_len, mta, mta_len, opt)) return -1;
     if (mta_len > 0 && (uint64_t) mta_len * sizeof(LrmMtaDev) > LRM_PACK_PIECE) { lrm_set_error("too many sequences"); return -1; }
     if (blob_bytes < pk.h.total_bytes) { lrm_set_error("blob buffer too small"); return -1; }
     // pieces are written in place: the "next buffer" is the piece's own position in the blob, so the gaps between
@@ -366,7 +464,8 @@ extern "C" int lrm_index_pack_blob(const lrm_dna_fmi *fmi, const lrm_lc_hash *lc
                    });
 }
 
-static int make_handle(lrm_index **out, void *d_blob, uint64_t bytes, int device, int owns, const LrmBlobHeader &h) {
+static int make_handle(lrm_index **out, void *d_blob, uint64_t bytes, int device, int owns, const LrmBlobHeader &h,
+                       const lrm_index_options *opt) {
     if (h.magic != LRM_BLOB_MAGIC || h.version != LRM_ABI_VERSION) { lrm_set_error("not an lrm index image (magic/version)"); return -1; }
     if (h.total_bytes > bytes) { lrm_set_error("index image truncated"); return -1; }
     lrm_index *ix = new (std::nothrow) lrm_index;
@@ -389,6 +488,9 @@ static int make_handle(lrm_index **out, void *d_blob, uint64_t bytes, int device
     ix->view.sa_shift = 0;
     for (uint64_t r = h.sa_ratio > 1 ? h.sa_ratio : 1; r > 1; r >>= 1) ix->view.sa_shift++;
     ix->n_peers = 1;
+    lrm_env_snapshot(&ix->env);                          // the LRM_* overrides are read here, once per handle
+    lrm_resolve_index_tune(opt, ix->env, &ix->itune);
+    lrm_resolve_map_tune(nullptr, ix->env, &ix->mtune);
     if (lrm_bs_prepare_index(ix)) { delete ix; return -1; }
     if (lrm_lcl_prepare_index(ix)) { lrm_bs_free_index(ix); delete ix; return -1; }
     *out = ix;
@@ -409,6 +511,10 @@ int lrm_require_device(int device) {
 #define require_device lrm_require_device
 
 extern "C" int lrm_index_upload_blob(lrm_index **out, const void *blob, uint64_t blob_bytes, int device) {
+    return lrm_index_upload_blob_opt(out, blob, blob_bytes, device, nullptr);
+}
+extern "C" int lrm_index_upload_blob_opt(lrm_index **out, const void *blob, uint64_t blob_bytes, int device,
+                                         const lrm_index_options *opt) {
     if (!out || !blob || blob_bytes < sizeof(LrmBlobHeader)) { lrm_set_error("bad blob"); return -1; }
     if (require_device(device)) return -1;
     LrmBlobHeader h;
@@ -416,16 +522,20 @@ extern "C" int lrm_index_upload_blob(lrm_index **out, const void *blob, uint64_t
     void *d = nullptr;
     HIPCHK(hipMalloc(&d, blob_bytes));
     if (hipMemcpy(d, blob, blob_bytes, hipMemcpyHostToDevice) != hipSuccess) { (void) hipFree(d); lrm_set_error("index upload failed"); return -1; }
-    if (make_handle(out, d, blob_bytes, device, 1, h)) { (void) hipFree(d); return -1; }
+    if (make_handle(out, d, blob_bytes, device, 1, h, opt)) { (void) hipFree(d); return -1; }
     return 0;
 }
 
 extern "C" int lrm_index_adopt_device(lrm_index **out, void *d_blob, uint64_t blob_bytes, int device) {
+    return lrm_index_adopt_device_opt(out, d_blob, blob_bytes, device, nullptr);
+}
+extern "C" int lrm_index_adopt_device_opt(lrm_index **out, void *d_blob, uint64_t blob_bytes, int device,
+                                          const lrm_index_options *opt) {
     if (!out || !d_blob || blob_bytes < sizeof(LrmBlobHeader)) { lrm_set_error("bad blob"); return -1; }
     if (require_device(device)) return -1;
     LrmBlobHeader h;
     HIPCHK(hipMemcpy(&h, d_blob, sizeof(h), hipMemcpyDeviceToHost));
-    return make_handle(out, d_blob, blob_bytes, device, 0, h);
+    return make_handle(out, d_blob, blob_bytes, device, 0, h, opt);
 }
 
 // pack + upload without a host copy of the image: two pinned chunks, the DMA of one overlaps the packing of the other
@@ -464,18 +574,24 @@ static int stream_image(const BlobPacker &pk, void *d_dst) {
     return 0;
 }
 
-extern "C" int lrm_index_upload(lrm_index **out, const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
-                                const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len, int device) {
+static int upload_one(lrm_index **out, const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
+                      const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len, int device,
+                      const lrm_index_options *opt) {
     if (!out || !fmi || !lch) { lrm_set_error("null argument"); return -1; }
     if (require_device(device)) return -1;
     BlobPacker pk;
-    if (pk.init(fmi, lch, sa, content, con_len, mta, mta_len)) return -1;
+    if (pk.init(fmi, lch, sa, content, con_len, mta, mta_len, opt)) return -1;
     if (mta_len > 0 && (uint64_t) mta_len * sizeof(LrmMtaDev) > LRM_PACK_PIECE) { lrm_set_error("too many sequences"); return -1; }
     const uint64_t bytes = pk.h.total_bytes;
     void *d = nullptr;
     if (hipMalloc(&d, bytes) != hipSuccess) { (void) hipGetLastError(); lrm_set_error("hipMalloc of the %llu-byte index image failed", (unsigned long long) bytes); return -1; }
-    if (stream_image(pk, d) || make_handle(out, d, bytes, device, 1, pk.h)) { (void) hipFree(d); return -1; }
+    if (stream_image(pk, d) || make_handle(out, d, bytes, device, 1, pk.h, opt)) { (void) hipFree(d); return -1; }
     return 0;
+}
+
+extern "C" int lrm_index_upload(lrm_index **out, const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
+                                const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len, int device) {
+    return upload_one(out, fmi, lch, sa, content, con_len, mta, mta_len, device, nullptr);
 }
 
 // the same into device memory the caller owns (e.g. a buffer that is then broadcast to the other ranks and
@@ -483,10 +599,15 @@ extern "C" int lrm_index_upload(lrm_index **out, const lrm_dna_fmi *fmi, const l
 extern "C" int lrm_index_pack_device(const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
                                      const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len,
                                      void *d_blob, uint64_t blob_bytes, int device) {
+    return lrm_index_pack_device_opt(fmi, lch, sa, content, con_len, mta, mta_len, d_blob, blob_bytes, device, nullptr);
+}
+extern "C" int lrm_index_pack_device_opt(const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
+                                         const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len,
+                                         void *d_blob, uint64_t blob_bytes, int device, const lrm_index_options *opt) {
     if (!fmi || !lch || !d_blob) { lrm_set_error("null argument"); return -1; }
     if (require_device(device)) return -1;
     BlobPacker pk;
-    if (pk.init(fmi, lch, sa, content, con_len, mta, mta_len)) return -1;
+    if (pk.init(fmi, lch, sa, content, con_len, mta, mta_len, opt)) return -1;
     if (mta_len > 0 && (uint64_t) mta_len * sizeof(LrmMtaDev) > LRM_PACK_PIECE) { lrm_set_error("too many sequences"); return -1; }
     if (blob_bytes < pk.h.total_bytes) { lrm_set_error("device buffer too small for the image"); return -1; }
     return stream_image(pk, d_blob);
@@ -555,11 +676,16 @@ int rccl_broadcast(const std::vector<int> &devs, const std::vector<void *> &bufs
 extern "C" int lrm_index_upload_multi(lrm_index **out, const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
                                       const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len,
                                       const int *devices, int ngpus) {
+    return lrm_index_upload_opt(out, fmi, lch, sa, content, con_len, mta, mta_len, devices, ngpus, nullptr);
+}
+extern "C" int lrm_index_upload_opt(lrm_index **out, const lrm_dna_fmi *fmi, const lrm_lc_hash *lch, const lrm_sa_mem *sa,
+                                    const char *content, uint64_t con_len, const lrm_mta_entry *mta, int mta_len,
+                                    const int *devices, int ngpus, const lrm_index_options *opt) {
     if (!out || ngpus < 1 || ngpus > 64) { lrm_set_error("bad argument (1 <= ngpus <= 64)"); return -1; }
     std::vector<int> devs((size_t) ngpus);
     for (int i = 0; i < ngpus; ++i) devs[i] = devices ? devices[i] : i;
     lrm_index *root = nullptr;
-    if (lrm_index_upload(&root, fmi, lch, sa, content, con_len, mta, mta_len, devs[0])) return -1;
+    if (upload_one(&root, fmi, lch, sa, content, con_len, mta, mta_len, devs[0], opt)) return -1;
     if (ngpus == 1) { *out = root; return 0; }
     const uint64_t bytes = root->blob_bytes;
     std::vector<void *> bufs((size_t) ngpus, nullptr);
@@ -591,7 +717,7 @@ extern "C" int lrm_index_upload_multi(lrm_index **out, const lrm_dna_fmi *fmi, c
     root->n_peers = 1;
     for (int i = 1; i < ngpus; ++i) {
         lrm_index *rep = nullptr;
-        if (lrm_require_device(devs[i]) || make_handle(&rep, bufs[i], bytes, devs[i], 1, root->hdr)) {
+        if (lrm_require_device(devs[i]) || make_handle(&rep, bufs[i], bytes, devs[i], 1, root->hdr, opt)) {
             for (int k = i; k < ngpus; ++k) { (void) hipSetDevice(devs[k]); (void) hipFree(bufs[k]); }
             lrm_index_free(root);                  // frees the replicas made so far
             return -1;
@@ -620,6 +746,37 @@ extern "C" int lrm_debug_rccl_selftest(int device, uint64_t bytes) {
     if (rc == 0 && back != h) { lrm_set_error("RCCL self-test: buffer changed by a 1-rank broadcast"); rc = -1; }
     (void) hipFree(d);
     return rc;
+}
+
+extern "C" int lrm_index_set_map_options(lrm_index *idx, const lrm_map_options *opt) {
+    if (!idx) { lrm_set_error("null argument"); return -1; }
+    for (int r = 0; r < idx->n_peers; ++r) {
+        lrm_index *ix = idx->peers ? idx->peers[r] : idx;
+        lrm_resolve_map_tune(opt, ix->env, &ix->mtune);
+        ix->mtune.t3_limit = ix->dbg_t3_limit; ix->mtune.t3_slots = ix->dbg_t3_slots;
+    }
+    return 0;
+}
+// tuning sessions (tools/*_probe.py): take the LRM_* variables as they stand NOW for the batch calls of this handle
+extern "C" int lrm_debug_reload_env(lrm_index *idx) {
+    if (!idx) { lrm_set_error("null argument"); return -1; }
+    for (int r = 0; r < idx->n_peers; ++r) {
+        lrm_index *ix = idx->peers ? idx->peers[r] : idx;
+        lrm_env_snapshot(&ix->env);
+        lrm_resolve_map_tune(nullptr, ix->env, &ix->mtune);
+        ix->mtune.t3_limit = ix->dbg_t3_limit; ix->mtune.t3_slots = ix->dbg_t3_slots;
+    }
+    return 0;
+}
+extern "C" int lrm_debug_set_vote_limits(lrm_index *idx, uint32_t t3_limit, uint32_t t3_slots) {
+    if (!idx) { lrm_set_error("null argument"); return -1; }
+    if (t3_slots && (t3_slots < 8 || t3_slots > LRM_VOTE_T3_SLOTS)) { lrm_set_error("t3_slots outside [8, %d]", LRM_VOTE_T3_SLOTS); return -1; }
+    for (int r = 0; r < idx->n_peers; ++r) {
+        lrm_index *ix = idx->peers ? idx->peers[r] : idx;
+        ix->dbg_t3_limit = ix->mtune.t3_limit = t3_limit;
+        ix->dbg_t3_slots = ix->mtune.t3_slots = t3_slots;
+    }
+    return 0;
 }
 
 extern "C" int lrm_index_replicas(const lrm_index *idx) { return idx ? idx->n_peers : 0; }
@@ -768,7 +925,7 @@ extern "C" int lrm_seed_batch_dev(lrm_index *idx, lrm_workspace *ws, const char 
     if (stride < max_len) { lrm_set_error("stride %llu < max_len %u", (unsigned long long) stride, max_len); return -1; }
     if (lrm_ws_take_error(ws)) return -2;
     HIPCHK(hipSetDevice(idx->device));
-    return lrm_launch_seed(idx, ws, d_reads, stride, d_lens, n, max_len, p.seed_len, p.thres, d_best, stream);
+    return lrm_launch_seed(idx, ws, d_reads, stride, d_lens, n, max_len, p.seed_len, p.thres, d_best, idx->mtune, stream);
 }
 
 extern "C" int lrm_extend_batch_dev(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint64_t stride,
@@ -783,7 +940,7 @@ extern "C" int lrm_extend_batch_dev(lrm_index *idx, lrm_workspace *ws, char *d_r
     if (lrm_ws_take_error(ws)) return -2;
     HIPCHK(hipSetDevice(idx->device));
     return lrm_launch_extend(idx, ws, d_reads, stride, d_lens, n, max_len, d_best, gp, d_store, store_stride,
-                             d_n_ops, d_score, d_meta, d_meta_r, stream);
+                             d_n_ops, d_score, d_meta, d_meta_r, idx->mtune, stream);
 }
 
 extern "C" int lrm_workspace_stats(lrm_workspace *ws, lrm_stats *out, void *stream) {

@@ -78,6 +78,32 @@ struct LrmIndexView {
     int32_t pad_;
 };
 
+// ---- resolved choices of a handle ------------------------------------------------------------------------------
+// Options come from the caller (lrm_index_options / lrm_map_options); LRM_* environment variables are tuning
+// OVERRIDES, read ONCE when a handle is created (LrmEnv) and never per call or per launch.
+struct LrmEnv {                     // the LRM_* variables as they stood when the handle was created
+    static constexpr int MAXV = 32;
+    const char *name[MAXV];
+    long long val[MAXV];
+    int n;
+    bool get(const char *key, long long *out) const;
+};
+void lrm_env_snapshot(LrmEnv *e);
+struct LrmIndexTune {
+    int sa_ratio;                   // 1: full SA; 2..64: sampled
+    int lc_long, lc_long_max, lc_pair;
+    uint64_t lcx_threshold;
+};
+struct LrmMapTune {
+    int dense, gact_impl, seed_rounds, direct_rows;
+    uint32_t slice_reads, sub_batches, group_subs, bs_waves;
+    uint32_t ss_items, vote_vg, vote_t1, vote_u, vote_load;      // kernel tuning (environment only; measured defaults)
+    uint32_t t3_limit, t3_slots;                                 // lrm_debug_set_vote_limits (tests)
+    int ext_streams, seed_streams, verbose;
+};
+void lrm_resolve_index_tune(const lrm_index_options *opt, const LrmEnv &env, LrmIndexTune *out);
+void lrm_resolve_map_tune(const lrm_map_options *opt, const LrmEnv &env, LrmMapTune *out);
+
 struct LrmHostCtx;            // lrm_host.hip: per-handle state of the host-buffer entry points
 struct lrm_index {
     void *d_blob;
@@ -95,6 +121,10 @@ struct lrm_index {
     // on the group handle partitions the reads by bases and runs one host thread per replica.
     int n_peers;
     lrm_index **peers;
+    LrmEnv env;               // LRM_* overrides as read at creation
+    LrmIndexTune itune;
+    LrmMapTune mtune;         // default options of the batch calls on this handle (lrm_index_set_map_options)
+    uint32_t dbg_t3_limit, dbg_t3_slots;   // lrm_debug_set_vote_limits (0 = default)
 };
 
 // Per-(read,phase) vote result written by the vote kernels.
@@ -184,13 +214,13 @@ struct LrmBsArgs {
 uint64_t lrm_bs_planar_words(uint64_t len);
 uint64_t lrm_bs_code_words(uint32_t max_len);
 uint64_t lrm_bs_ckpt_words(uint64_t n);
-bool lrm_bs_wanted(lrm_gact_params gp, uint64_t n);      // W <= 128 and (LRM_GACT_IMPL=4 or automatic with a large batch)
+bool lrm_bs_wanted(lrm_gact_params gp, uint64_t n, int gact_impl);      // W <= 128 and (impl 4, or automatic with a large batch)
 int lrm_bs_pack_reads(const char *d_reads, uint64_t stride, const uint32_t *d_lens, uint64_t n, uint32_t max_len,
                       uint64_t *d_qpl, uint64_t wpr, uint32_t *d_flags, void *stream);
 int lrm_bs_pack_text(const char *d_text, uint64_t len, uint64_t *d_out, uint32_t *d_flag, void *stream);
 int lrm_bs_launch(const LrmBsArgs *bs, const uint32_t *d_lens, const lrm_seq_meta *d_meta, const int32_t *d_meta_r,
                   const uint32_t *d_tlens, uint64_t n, int T, int O, int W, uint8_t *d_store, uint64_t store_stride,
-                  int32_t *d_n_ops, int32_t *d_score, LrmDevCounters *counters, void *stream);
+                  int32_t *d_n_ops, int32_t *d_score, LrmDevCounters *counters, uint32_t max_waves, void *stream);
 int lrm_bs_prepare_index(lrm_index *idx);
 int lrm_lcl_prepare_index(lrm_index *idx);       // seed_kernels.hip: the long seed table
 void lrm_bs_free_index(lrm_index *idx);
@@ -200,9 +230,6 @@ void lrm_set_error(const char *fmt, ...);
 // (affinity mask, cgroup CPU quota) -- a GPU box hands a job 16 of its 256 hardware threads, and a team of 256 on a
 // quota of 16 is throttled to a crawl.  OMP_NUM_THREADS still lowers it.
 int lrm_host_threads(void);
-// Cap on the long seed table's k-mer length for index uploads issued by THIS thread (0 = none).  The 64 GiB 16-mer
-// table costs 0.7-2 s at upload and repays it after a few hundred Gbp of reads; lrm_accaln caps it for small inputs.
-extern thread_local int lrm_lcl_max_hl;
 int lrm_require_device(int device);
 int lrm_workspace_create_parts(lrm_workspace **out, lrm_index *idx, uint64_t n_max, uint32_t max_len, uint32_t seed_len,
                                uint32_t thres, int parts);
@@ -214,12 +241,12 @@ void lrm_time_end(lrm_workspace *ws, void *stream);
 // launchers implemented in the .hip files (all asynchronous on `stream`)
 int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint64_t stride,
                     const uint32_t *d_lens, uint64_t n, uint32_t max_len, uint32_t seed_len,
-                    uint32_t thres, lrm_entry *d_best, void *stream);
+                    uint32_t thres, lrm_entry *d_best, const LrmMapTune &mt, void *stream);
 int lrm_launch_extend(lrm_index *idx, lrm_workspace *ws, char *d_reads, uint64_t stride,
                       const uint32_t *d_lens, uint64_t n, uint32_t max_len,
                       const lrm_entry *d_best, lrm_gact_params gp, uint8_t *d_store,
                       uint64_t store_stride, int32_t *d_n_ops, int32_t *d_score,
-                      lrm_seq_meta *d_meta, int32_t *d_meta_r, void *stream);
+                      lrm_seq_meta *d_meta, int32_t *d_meta_r, const LrmMapTune &mt, void *stream);
 int lrm_launch_debug_seed(lrm_index *idx, const char *d_read, uint32_t len, uint32_t seed_len,
                           uint64_t *d_reads2, uint64_t words, int32_t *d_j, uint64_t *d_rr,
                           uint64_t *d_k, uint64_t *d_l, uint64_t cap, void *stream);

@@ -219,8 +219,8 @@ __global__ __launch_bounds__(256) void lcl_build_kernel(LrmIndexView ix, int hl,
 // 14 (4 GiB, leaving 8), 13 (1 GiB).  LRM_LC_LONG = 0 (off) | 13..17, LRM_LC_PAIR = 0 | 1 override.  A table that
 // cannot be allocated is skipped: results never depend on it.  Cost at upload [r2]: 16 GiB and below ~10 ms, the 64 GiB
 // table 0.65 s (2 s when the memory was freed a moment ago) -- repaid after a few hundred Gbp of reads, so callers that
-// know their run is short cap the length (lrm_lcl_max_hl; lrm_accaln does it from the size of the reads file).
-thread_local int lrm_lcl_max_hl = 0;
+// know their run is short cap the length (lrm_index_options.lc_long_max; lrm_accaln does it from the size of the reads
+// file).
 
 int lrm_lcl_prepare_index(lrm_index *idx) {
     const uint64_t L = idx->view.length;
@@ -230,9 +230,10 @@ int lrm_lcl_prepare_index(lrm_index *idx) {
     static const struct { int hl; uint64_t spare; } ladder[] = {{16, 64ull << 30}, {15, 32ull << 30}, {14, 8ull << 30}};
     for (const auto &c : ladder)
         if ((uint64_t) free_b >= (16ull << (2 * c.hl)) + c.spare) { hl = c.hl; break; }
-    if (lrm_lcl_max_hl >= 13 && hl > lrm_lcl_max_hl) hl = lrm_lcl_max_hl;       // the caller expects a short run
-    if (const char *e = getenv("LRM_LC_LONG")) hl = atoi(e);
-    if (const char *e = getenv("LRM_LC_PAIR")) pair = atoi(e) != 0;
+    const LrmIndexTune &tu = idx->itune;
+    if (tu.lc_long_max >= 13 && hl > tu.lc_long_max) hl = tu.lc_long_max;      // the caller expects a short run
+    if (tu.lc_long >= 0) hl = tu.lc_long;
+    if (tu.lc_pair >= 0) pair = tu.lc_pair != 0;
     if (hl <= idx->view.hlen || hl > 17 || L < 2) return 0;
     uint64_t *d = nullptr;
     const uint64_t slots = (pair ? 2ull : 1ull) << (2 * hl);
@@ -943,7 +944,7 @@ __global__ __launch_bounds__(256) void decide_kernel(const LrmPhaseRes *__restri
 
 int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint64_t stride,
                     const uint32_t *d_lens, uint64_t n, uint32_t max_len, uint32_t seed_len,
-                    uint32_t thres, lrm_entry *d_best, void *stream_) {
+                    uint32_t thres, lrm_entry *d_best, const LrmMapTune &mt, void *stream_) {
     hipStream_t stream = (hipStream_t) stream_;
     if (n == 0) return 0;
     const int P = (int) seed_len + 1;
@@ -971,35 +972,27 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
         lrm_set_error("read too long for the vote order key: cap_q %u << %u bits exceeds 32 bits", cap_q, tbits);
         return -1;
     }
-    uint32_t t3_limit = T3_LIMIT, t3_slots = T3_SLOTS;
-    if (const char *e = getenv("LRM_T3_LIMIT")) {        // test knobs: a pass limit above the table size and a
-        const long long v = atoll(e);                     // small table force overflows of the multi-pass tier
-        if (v >= 1) t3_limit = (uint32_t) v;
-    }
-    if (const char *e = getenv("LRM_T3_SLOTS")) {
-        const long long v = atoll(e);
-        if (v >= 8 && v <= T3_SLOTS) t3_slots = (uint32_t) v;
-    }
-    // tuning knobs (measured defaults; tools/seed_probe.py sweeps them)
-    uint32_t vg = VG, t1_limit = T1_LIMIT;
-    int vote_u = 2;
-    if (const char *e = getenv("LRM_VOTE_VG")) { const int v = atoi(e); if (v >= 1 && v <= VG_MAX) vg = (uint32_t) v; }
-    if (const char *e = getenv("LRM_VOTE_T1")) { const int v = atoi(e); if (v >= 0 && v <= T1_LIMIT) t1_limit = (uint32_t) v; }
-    if (const char *e = getenv("LRM_VOTE_U")) vote_u = atoi(e);
-    uint32_t vote_load = 50;        // percent of the table slots an item is sized for (when the table allows): at 75 % the
-                                    // linear probes of the slowest lane cost +1.7 ms per Gbp [r2], at 90 % +4.4 ms
-    if (const char *e = getenv("LRM_VOTE_LOAD")) { const int v = atoi(e); if (v >= 10 && v <= 95) vote_load = (uint32_t) v; }
+    // (tests force overflows of the multi-pass tier with a pass limit above the table size and a small table:
+    //  lrm_debug_set_vote_limits)
+    const uint32_t t3_limit = mt.t3_limit ? mt.t3_limit : (uint32_t) T3_LIMIT;
+    const uint32_t t3_slots = mt.t3_slots >= 8 && mt.t3_slots <= T3_SLOTS ? mt.t3_slots : (uint32_t) T3_SLOTS;
+    // tuning knobs (measured defaults; tools/seed_probe.py sweeps them through the environment, read at handle creation)
+    const uint32_t vg = mt.vote_vg >= 1 && mt.vote_vg <= VG_MAX ? mt.vote_vg : VG;
+    const uint32_t t1_limit = mt.vote_t1 <= T1_LIMIT ? mt.vote_t1 : (uint32_t) T1_LIMIT;
+    const int vote_u = (int) mt.vote_u;
+    const uint32_t vote_load = mt.vote_load;        // percent of the table slots an item is sized for (when the table allows): at 75 % the
+                                                    // linear probes of the slowest lane cost +1.7 ms per Gbp [r2], at 90 % +4.4 ms
     // Rounds.  Phase 0 alone first, then phases 1..s for the reads it did not decide, saves 20/21 of the work on clean
     // reads; on noisy reads phase 0 decides nothing and the split only costs a second set of launches whose phase-0
     // wavefronts hold seeds 21 positions apart (no shared fate).  The workspace remembers how many reads the previous
     // batch decided in phase 0 (copied back asynchronously, never waited for): below 2 % the next batch runs ALL phases
-    // in one round.  Speculative evaluation is exact, so the results do not depend on the choice.  LRM_SEED_ROUNDS=1|2.
+    // in one round.  Speculative evaluation is exact, so the results do not depend on the choice.  lrm_map_options.seed_rounds.
     bool single = false;
     {
         const volatile uint64_t *hist = reinterpret_cast<const volatile uint64_t *>(ws->h_err + 2);
         const uint64_t d0 = *hist;
         if (ws->hist_n >= 64 && d0 * 50 < ws->hist_n) single = true;
-        if (const char *e = getenv("LRM_SEED_ROUNDS")) single = atoi(e) == 1;
+        if (mt.seed_rounds == 1 || mt.seed_rounds == 2) single = mt.seed_rounds == 1;
         if (P == 1) single = true;
     }
     for (int round = single ? 1 : 0; round < 2; ++round) {
@@ -1008,8 +1001,7 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
         if (lo > hi) break;
         int np = hi - lo + 1;
         const uint8_t *dec = round == 0 || single ? nullptr : ws->d_decided;
-        uint32_t ss_items = 2048u;
-        if (const char *e = getenv("LRM_SS_ITEMS")) { const int v = atoi(e); if (v == 1024 || v == 2048 || v == 4096) ss_items = (uint32_t) v; }   // tuning knob
+        const uint32_t ss_items = mt.ss_items;
         uint32_t bpr = (uint32_t) (((uint64_t) np * cap_q + ss_items - 1) / ss_items);
         uint64_t blocks = n * bpr;
         if (blocks > 0x7fffffffull) { lrm_set_error("seed_search grid too large: split the batch"); return -1; }

@@ -114,27 +114,28 @@ class HostIndex:
         return [(self.h.mta[i].name.decode() if self.h.mta[i].name else "", int(self.h.mta[i].offset),
                  int(self.h.mta[i].seq_len)) for i in range(self.mta_len)]
 
-    def blob_bytes(self):
-        return int(lib.lrm_index_blob_bytes(self.length, self.hlen, self.mta_len))
+    def blob_bytes(self, **opts):
+        return int(lib.lrm_index_blob_bytes_opt(self.length, self.hlen, self.mta_len, C.byref(capi.index_options(**opts))))
 
-    def pack_device(self, device=0):
-        """The image packed straight into a torch uint8 CUDA tensor (no host copy): broadcast it, then adopt."""
+    def pack_device(self, device=0, **opts):
+        """The image packed straight into a torch uint8 CUDA tensor (no host copy): broadcast it, then adopt.
+        opts: lrm_index_options fields (sa_sampled, lcx_threshold)."""
         import torch
-        n = self.blob_bytes()
+        n = self.blob_bytes(**opts)
         t = torch.empty(n, dtype=torch.uint8, device=torch.device("cuda", device))
-        check(lib.lrm_index_pack_device(C.byref(self.h.fmi), C.byref(self.h.lch), C.byref(self.h.sa), self.h.content,
-                                        self.h.con_len, self.h.mta, self.h.mta_len, t.data_ptr(), n, device),
-              "lrm_index_pack_device")
+        check(lib.lrm_index_pack_device_opt(C.byref(self.h.fmi), C.byref(self.h.lch), C.byref(self.h.sa), self.h.content,
+                                            self.h.con_len, self.h.mta, self.h.mta_len, t.data_ptr(), n, device,
+                                            C.byref(capi.index_options(**opts))), "lrm_index_pack_device_opt")
         return t
 
-    def pack_blob(self, out=None):
+    def pack_blob(self, out=None, **opts):
         """Serialise to the device image in host memory (numpy uint8)."""
-        n = self.blob_bytes()
+        n = self.blob_bytes(**opts)
         if out is None:
             out = np.empty(n, dtype=np.uint8)
-        check(lib.lrm_index_pack_blob(C.byref(self.h.fmi), C.byref(self.h.lch), C.byref(self.h.sa), self.h.content,
-                                      self.h.con_len, self.h.mta, self.h.mta_len, out.ctypes.data, n),
-              "lrm_index_pack_blob")
+        check(lib.lrm_index_pack_blob_opt(C.byref(self.h.fmi), C.byref(self.h.lch), C.byref(self.h.sa), self.h.content,
+                                          self.h.con_len, self.h.mta, self.h.mta_len, out.ctypes.data, n,
+                                          C.byref(capi.index_options(**opts))), "lrm_index_pack_blob_opt")
         return out
 
 
@@ -146,40 +147,45 @@ class DeviceIndex:
         self._keep = keep      # e.g. the torch tensor that owns an adopted blob
 
     @classmethod
-    def upload(cls, host: HostIndex, device=0):
-        hnd = C.c_void_p()
-        check(lib.lrm_index_upload(C.byref(hnd), C.byref(host.h.fmi), C.byref(host.h.lch), C.byref(host.h.sa),
-                                   host.h.content, host.h.con_len, host.h.mta, host.h.mta_len, device),
-              "lrm_index_upload")
-        return cls(hnd)
+    def upload(cls, host: HostIndex, device=0, **opts):
+        """opts: lrm_index_options fields (sa_sampled, lc_long, lc_long_max, lc_pair, lcx_threshold)."""
+        return cls.upload_multi(host, [device], **opts)
 
     @classmethod
-    def upload_multi(cls, host: HostIndex, devices):
-        """Multi-GPU group handle (lrm_index_upload_multi): one image per listed device, replicated over xGMI;
-        the batch calls shard the reads over the replicas."""
+    def upload_multi(cls, host: HostIndex, devices, **opts):
+        """One device, or a multi-GPU group handle (lrm_index_upload_opt): one image per listed device, replicated
+        over xGMI; the batch calls shard the reads over the replicas."""
         hnd = C.c_void_p()
         devs = (C.c_int * len(devices))(*devices)
-        check(lib.lrm_index_upload_multi(C.byref(hnd), C.byref(host.h.fmi), C.byref(host.h.lch), C.byref(host.h.sa),
-                                         host.h.content, host.h.con_len, host.h.mta, host.h.mta_len, devs,
-                                         len(devices)), "lrm_index_upload_multi")
+        check(lib.lrm_index_upload_opt(C.byref(hnd), C.byref(host.h.fmi), C.byref(host.h.lch), C.byref(host.h.sa),
+                                       host.h.content, host.h.con_len, host.h.mta, host.h.mta_len, devs,
+                                       len(devices), C.byref(capi.index_options(**opts))), "lrm_index_upload_opt")
         return cls(hnd)
+
+    def set_map_options(self, **opts):
+        """Default lrm_map_options of the batch calls on this handle (no arguments: the automatic choices)."""
+        check(lib.lrm_index_set_map_options(self.handle, C.byref(capi.map_options(**opts))), "lrm_index_set_map_options")
+
+    def debug_set_vote_limits(self, t3_limit=0, t3_slots=0):
+        check(lib.lrm_debug_set_vote_limits(self.handle, t3_limit, t3_slots), "lrm_debug_set_vote_limits")
 
     @property
     def replicas(self):
         return int(lib.lrm_index_replicas(self.handle))
 
     @classmethod
-    def upload_blob(cls, blob: np.ndarray, device=0):
+    def upload_blob(cls, blob: np.ndarray, device=0, **opts):
         hnd = C.c_void_p()
-        check(lib.lrm_index_upload_blob(C.byref(hnd), blob.ctypes.data, blob.nbytes, device), "lrm_index_upload_blob")
+        check(lib.lrm_index_upload_blob_opt(C.byref(hnd), blob.ctypes.data, blob.nbytes, device,
+                                            C.byref(capi.index_options(**opts))), "lrm_index_upload_blob_opt")
         return cls(hnd)
 
     @classmethod
-    def adopt(cls, blob_tensor, device=0):
+    def adopt(cls, blob_tensor, device=0, **opts):
         """blob_tensor: torch uint8 CUDA tensor holding the image (e.g. after an RCCL broadcast)."""
         hnd = C.c_void_p()
-        check(lib.lrm_index_adopt_device(C.byref(hnd), blob_tensor.data_ptr(), blob_tensor.numel(), device),
-              "lrm_index_adopt_device")
+        check(lib.lrm_index_adopt_device_opt(C.byref(hnd), blob_tensor.data_ptr(), blob_tensor.numel(), device,
+                                             C.byref(capi.index_options(**opts))), "lrm_index_adopt_device_opt")
         return cls(hnd, keep=blob_tensor)
 
     def close(self):

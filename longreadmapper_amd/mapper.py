@@ -71,9 +71,69 @@ def pinned_free(arr):
     lib.lrm_host_free(arr.ctypes.data)
 
 
-def map_batch(index, reads, lens, seed_len=DEFAULT_SEED_LEN, thres=DEFAULT_THRES, gact=DEFAULT_GACT, store=None):
-    """PART 1 + PART 2 in one device pass (lrm_map_batch); `reads` is modified in place like extend_batch.
-    `store` may be a caller-provided (n, >= 2*max_len) uint8 array (e.g. pinned)."""
+class PendingBatch:
+    """A batch submitted with map_batch_submit: wait() blocks until its results are in the caller's arrays."""
+
+    def __init__(self, ticket, keep, n, dense):
+        self.ticket, self._keep, self.n, self.dense = ticket, keep, n, dense
+
+    def wait(self):
+        t, self.ticket = self.ticket, None
+        assert t is not None, "already waited for"
+        check(lib.lrm_map_batch_wait(t), "lrm_map_batch_wait")
+        best, store, cig, score, meta, meta_r = self._keep[:6]
+        n = self.n
+        cv = np.ctypeslib.as_array(C.cast(cig, C.POINTER(C.c_int32)), shape=(max(n, 1), 4))[:n]
+        out = dict(best=best, ops=store, n_ops=cv[:, 2].copy(), score=score, meta=meta, meta_r=meta_r)
+        if self.dense:          # cig[i].cigar = store_mem + off[i]
+            ptr = np.ctypeslib.as_array(C.cast(cig, C.POINTER(C.c_uint64)), shape=(max(n, 1), 2))[:n, 0]
+            out["ops_off"] = (ptr - np.uint64(store.ctypes.data)).astype(np.int64)
+        return out
+
+
+def ops_of(res, i):
+    """Op bytes of read i from a map_batch result in either layout."""
+    k = int(res["n_ops"][i])
+    if "ops_off" in res:
+        o = int(res["ops_off"][i])
+        return bytes(res["ops"].reshape(-1)[o:o + k])
+    return bytes(res["ops"][i, :k])
+
+
+def map_batch_submit(index, reads, lens, seed_len=DEFAULT_SEED_LEN, thres=DEFAULT_THRES, gact=DEFAULT_GACT, store=None,
+                     options=None):
+    """lrm_map_batch_submit: queues the batch and returns a PendingBatch.  `reads` is modified in place like
+    extend_batch once the batch runs; `store` may be a caller-provided (n, >= 2*max_len) uint8 array (e.g. pinned);
+    `options`: dict of lrm_map_options fields (None: the handle's defaults)."""
+    assert reads.dtype == np.uint8 and reads.flags.c_contiguous and reads.flags.writeable
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    n, stride = reads.shape
+    max_len = int(lens.max()) if n else 0
+    if store is None:
+        store = np.zeros((n, max((2 * max_len + 15) // 16 * 16, 16)), dtype=np.uint8)
+    store_stride = store.shape[1]
+    best = np.zeros(n, dtype=ENTRY_DT)
+    cig = (capi.Cigar * max(n, 1))()
+    score = np.zeros(n, dtype=np.int32)
+    meta = np.zeros(n, dtype=META_DT)
+    meta_r = np.zeros(n, dtype=np.int32)
+    opt = capi.map_options(**options) if options is not None else None
+    ticket = C.c_void_p()
+    check(lib.lrm_map_batch_submit(index.handle, reads.ctypes.data, stride, lens.ctypes.data, n,
+                                   capi.Params(n, seed_len, thres), capi.GactParams(*gact), best.ctypes.data,
+                                   C.cast(cig, C.c_void_p), store.ctypes.data, store_stride, score.ctypes.data,
+                                   meta.ctypes.data, meta_r.ctypes.data, C.byref(opt) if opt is not None else None,
+                                   C.byref(ticket)), "lrm_map_batch_submit")
+    dense = bool(opt.dense_results) if opt is not None else False
+    return PendingBatch(ticket, (best, store, cig, score, meta, meta_r, reads, lens), n, dense)
+
+
+def map_batch(index, reads, lens, seed_len=DEFAULT_SEED_LEN, thres=DEFAULT_THRES, gact=DEFAULT_GACT, store=None,
+              options=None):
+    """PART 1 + PART 2 in one device pass; `reads` is modified in place like extend_batch.
+    Without `options` this is lrm_map_batch (the handle's default options), with them submit + wait."""
+    if options is not None:
+        return map_batch_submit(index, reads, lens, seed_len, thres, gact, store, options).wait()
     assert reads.dtype == np.uint8 and reads.flags.c_contiguous and reads.flags.writeable
     lens = np.ascontiguousarray(lens, dtype=np.uint32)
     n, stride = reads.shape

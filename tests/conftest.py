@@ -43,3 +43,19 @@ def gpu():
     n = capi.lib.lrm_device_count()
     assert n > 0, "no HIP device visible: GPU tests need a real MI355X"
     return 0
+
+
+@pytest.fixture
+def map_options():
+    """Sets lrm_map_options defaults on device-index handles for the duration of a test (lrm_index_set_map_options);
+    the automatic choices come back afterwards."""
+    touched = []
+
+    def _set(di, **opts):
+        di.set_map_options(**opts)
+        if di not in touched:
+            touched.append(di)
+    yield _set
+    for di in touched:
+        if di.handle:
+            di.set_map_options()

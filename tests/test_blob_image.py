@@ -80,13 +80,12 @@ def test_sa_values_beyond_32_bits_survive_packing():
 
 
 @pytest.mark.parametrize("ratio", [2, 4, 64])
-def test_sampled_sa_image(monkeypatch, ratio):
-    """LRM_SA_SAMPLED=r: the [sa] section holds rows i*r only -- for r = 4 exactly the reference's csa table
+def test_sampled_sa_image(ratio):
+    """lrm_index_options.sa_sampled = r: the [sa] section holds rows i*r only -- for r = 4 exactly the reference's csa table
     (fmidx.c:153-163) -- and the image shrinks accordingly."""
     hi = index.HostIndex.build([synth.reference(9001, seed=4)], hlen=5)
     full = hi.blob_bytes()
-    monkeypatch.setenv("LRM_SA_SAMPLED", str(ratio))
-    blob = hi.pack_blob()
+    blob = hi.pack_blob(sa_sampled=ratio)
     h = _header(blob)
     L = hi.length
     assert h["sa_ratio"] == ratio and h["sa_len"] == (L + ratio - 1) // ratio and len(blob) < full
@@ -94,8 +93,8 @@ def test_sampled_sa_image(monkeypatch, ratio):
     assert np.array_equal(got, hi.sa()[::ratio])
     if ratio == 4:
         assert np.array_equal(got, hi.csa()[:len(got)])
-    monkeypatch.setenv("LRM_SA_SAMPLED", "3")           # not a power of two: ignored, full SA
-    assert hi.blob_bytes() == full
+    assert hi.blob_bytes(sa_sampled=3) == full       # not a power of two: ignored, full SA
+    assert hi.blob_bytes(sa_sampled=ratio) == len(blob)
 
 
 def test_pair_end_is_the_reference_stub():

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_abi_version_and_struct_layouts():
-    assert capi.lib.lrm_abi_version() == 2
+    assert capi.lib.lrm_abi_version() == 3
     assert C.sizeof(capi.Entry) == 24 and C.sizeof(capi.Params) == 16
     assert C.sizeof(capi.DnaFmi) == 64 and C.sizeof(capi.LcHash) == 24 and C.sizeof(capi.SaMem) == 24
     assert C.sizeof(capi.MtaEntry) == 40 and C.sizeof(capi.SeqMeta) == 24 and C.sizeof(capi.Cigar) == 16

@@ -34,22 +34,85 @@ def ont(gpu):
     di.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"LRM_HOST_SUBS": "4"}, {"LRM_HOST_SLICE": "9", "LRM_HOST_SUBS": "2"}])
-def test_map_batch_equals_the_two_calls_and_the_oracle(ont, monkeypatch, env):
-    """lrm_map_batch = lrm_seed_batch + lrm_extend_batch in one device pass (one upload of the reads)."""
+def _dense_rows(got):
+    """A dense-layout result as rows, so that _assert_ext_equal can compare it."""
+    n = len(got["n_ops"])
+    width = int(got["n_ops"].max()) if n else 0
+    rows = np.zeros((n, max(width, 1)), dtype=np.uint8)
+    for i in range(n):
+        k = int(got["n_ops"][i])
+        rows[i, :k] = np.frombuffer(mapper.ops_of(got, i), dtype=np.uint8)
+    return dict(got, ops=rows)
+
+
+@pytest.mark.parametrize("opts", [None, {}, {"sub_batches": 4}, {"slice_reads": 9, "sub_batches": 2},
+                                  {"dense_results": 1}, {"dense_results": 1, "slice_reads": 13, "sub_batches": 3, "group_subs": 1},
+                                  {"direct_rows": 0}, {"direct_rows": 1}])
+def test_map_batch_equals_the_two_calls_and_the_oracle(ont, opts):
+    """lrm_map_batch = lrm_seed_batch + lrm_extend_batch in one device pass (one upload of the reads), in every result
+    mode of lrm_map_options: rows / dense, any slicing, device row writes or host scatter."""
     sc, di, oi, best, ext, r_cpu = ont
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
     r = sc["reads"].copy()
-    got = mapper.map_batch(di, r, sc["lens"], sc["seed_len"], sc["thres"])
+    got = mapper.map_batch(di, r, sc["lens"], sc["seed_len"], sc["thres"], options=opts)
+    if opts and opts.get("dense_results"):
+        # cig[i].cigar points into store_mem, 16-byte aligned, ascending, inside the rows of the read's group
+        off = got["ops_off"][got["n_ops"] > 0]
+        assert (off % 16 == 0).all() and (np.diff(off) > 0).all()
+        got = _dense_rows(got)
     assert np.array_equal(got["best"], best)
-    _assert_ext_equal(got, ext, len(best), str(env))
+    _assert_ext_equal(got, ext, len(best), str(opts))
     assert np.array_equal(r, r_cpu)                      # reverse-strand reads rev-comped in the caller's buffer
 
 
-def test_map_batch_with_pinned_caller_buffers(ont, monkeypatch):
-    """Buffers from lrm_host_alloc are handed to the DMA engines directly (no staging copy): same results; also with
-    LRM_HOST_DIRECT=1, where the device writes the result rows straight into the pinned caller buffers."""
+@pytest.mark.parametrize("opts", [{}, {"dense_results": 1}, {"dense_results": 1, "direct_rows": 0}])
+@pytest.mark.parametrize("pinned", [False, True])
+def test_two_batches_in_flight(ont, opts, pinned):
+    """lrm_map_batch_submit / lrm_map_batch_wait: three batches submitted back to back (two in flight on the device,
+    the third queued), each with its own caller buffers; every one of them equals the synchronous call and the
+    oracle, whatever the order of the waits."""
+    sc, di, oi, best, ext, r_cpu = ont
+    n, stride = sc["reads"].shape
+    bufs, pend = [], []
+    try:
+        for k in range(3):
+            if pinned:
+                r = mapper.pinned_empty((n, stride))
+                st = mapper.pinned_empty((n, (2 * (stride - 1) + 15) // 16 * 16))
+                st[:] = 0
+            else:
+                r, st = np.empty((n, stride), dtype=np.uint8), None
+            r[:] = sc["reads"]
+            bufs.append((r, st))
+            pend.append(mapper.map_batch_submit(di, r, sc["lens"], sc["seed_len"], sc["thres"], store=st, options=opts))
+        for k in (1, 0, 2):
+            got = pend[k].wait()
+            if opts.get("dense_results"):
+                got = _dense_rows(got)
+            assert np.array_equal(got["best"], best)
+            _assert_ext_equal(got, ext, n, "batch %d %s" % (k, opts))
+            assert np.array_equal(bufs[k][0], r_cpu)
+    finally:
+        for p in pend:
+            if p.ticket is not None:
+                p.wait()
+        if pinned:
+            for r, st in bufs:
+                mapper.pinned_free(r)
+                mapper.pinned_free(st)
+
+
+def test_dense_results_need_an_aligned_stride(ont):
+    sc, di, oi, best, ext, r_cpu = ont
+    r = sc["reads"].copy()
+    n, stride = r.shape
+    st = np.zeros((n, 2 * (stride - 1) + 6), dtype=np.uint8)
+    with pytest.raises(capi.LrmError, match="multiple of 16"):
+        mapper.map_batch(di, r, sc["lens"], sc["seed_len"], sc["thres"], store=st, options={"dense_results": 1})
+
+
+def test_map_batch_with_pinned_caller_buffers(ont):
+    """Buffers from lrm_host_alloc are handed to the DMA engines directly (no staging copy) and the device writes the
+    result rows straight into them: same results; also with direct_rows = 0 (dense DMA + host scatter)."""
     sc, di, oi, best, ext, r_cpu = ont
     n, stride = sc["reads"].shape
     r = mapper.pinned_empty((n, stride))
@@ -61,13 +124,12 @@ def test_map_batch_with_pinned_caller_buffers(ont, monkeypatch):
         assert np.array_equal(got["best"], best)
         _assert_ext_equal(got, ext, n, "pinned")
         assert np.array_equal(r, r_cpu)
-        monkeypatch.setenv("LRM_HOST_DIRECT", "1")
-        r[:] = sc["reads"]
-        store[:] = 0
-        got = mapper.map_batch(di, r, sc["lens"], sc["seed_len"], sc["thres"], store=store)
-        monkeypatch.delenv("LRM_HOST_DIRECT")
-        assert np.array_equal(got["best"], best) and np.array_equal(r, r_cpu)
-        _assert_ext_equal(got, ext, n, "pinned, direct device writes")
+        for direct in (0, 1):
+            r[:] = sc["reads"]
+            store[:] = 0
+            got = mapper.map_batch(di, r, sc["lens"], sc["seed_len"], sc["thres"], store=store, options={"direct_rows": direct})
+            assert np.array_equal(got["best"], best) and np.array_equal(r, r_cpu)
+            _assert_ext_equal(got, ext, n, "pinned, direct_rows=%d" % direct)
         # registered caller memory (what a maintainer does with the malloc'd buffers of alnmain.c:297-320)
         r2 = np.ascontiguousarray(sc["reads"].copy())
         capi.check(capi.lib.lrm_host_register(r2.ctypes.data, r2.nbytes), "lrm_host_register")
@@ -82,8 +144,8 @@ def test_map_batch_with_pinned_caller_buffers(ont, monkeypatch):
         mapper.pinned_free(store)
 
 
-def test_vote_overflow_is_reported_from_any_sub_batch(gpu, monkeypatch):
-    """LRM_T3_LIMIT above the table size forces the multi-pass tier into one pass and LRM_T3_SLOTS shrinks its
+def test_vote_overflow_is_reported_from_any_sub_batch(gpu):
+    """lrm_debug_set_vote_limits: a pass limit above the table size forces the multi-pass tier into one pass and a small
     table: items with more distinct buckets than slots overflow.  The error word is sticky, so an overflow in sub-batch 0 of 4 fails the call
     (it used to be erased by the next launch), and a *_dev caller gets it on the next call."""
     import torch
@@ -97,29 +159,25 @@ def test_vote_overflow_is_reported_from_any_sub_batch(gpu, monkeypatch):
         reads[i, :sc["lens"][i]] = rnd[i - 10, :sc["lens"][i]]
     sc["reads"] = reads
     try:
-        monkeypatch.setenv("LRM_T3_LIMIT", "1000000")
-        monkeypatch.setenv("LRM_T3_SLOTS", "64")
-        monkeypatch.setenv("LRM_HOST_SUBS", "4")
+        di.set_map_options(sub_batches=4)
+        di.debug_set_vote_limits(1000000, 64)
         with pytest.raises(capi.LrmError, match="vote table overflow"):
             mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
         # the handle stays usable and the flag does not leak into the next (good) batch
-        monkeypatch.delenv("LRM_T3_LIMIT")
-        monkeypatch.delenv("LRM_T3_SLOTS")
+        di.debug_set_vote_limits(0, 0)
         oi = orc.OracleIndex.from_host_index(sc["hi"])
         want, _ = oi.seed_batch(sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
         got = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
         assert np.array_equal(got, want)
         # device-buffer API: the faulty batch returns 0 (asynchronous), the next call on the workspace fails
-        monkeypatch.setenv("LRM_T3_LIMIT", "1000000")
-        monkeypatch.setenv("LRM_T3_SLOTS", "64")
+        di.debug_set_vote_limits(1000000, 64)
         stride = sc["reads"].shape[1]
         dm = mapper.DeviceMapper(di, n, stride - 1, sc["seed_len"], sc["thres"], device=gpu)
         d_reads = torch.from_numpy(sc["reads"]).cuda()
         d_lens = torch.from_numpy(sc["lens"].astype(np.int32)).cuda()
         dm.seed(d_reads, d_lens)
         torch.cuda.synchronize()
-        monkeypatch.delenv("LRM_T3_LIMIT")
-        monkeypatch.delenv("LRM_T3_SLOTS")
+        di.debug_set_vote_limits(0, 0)
         with pytest.raises(capi.LrmError, match="vote table overflow"):
             dm.seed(d_reads, d_lens)
         dm.seed(d_reads, d_lens)                         # cleared by the failing call
@@ -163,19 +221,17 @@ def test_multi_gpu_group_handle_equals_one_gpu(ont, gpu, ngpus):
 
 
 @pytest.mark.parametrize("name", ["ont-2k", "repeats-ties", "repeats-overflow", "ragged"])
-@pytest.mark.parametrize("ratio", ["4", "32"])
-def test_sampled_sa_locate_mode(gpu, monkeypatch, name, ratio):
-    """LRM_SA_SAMPLED=r keeps SA rows i*r only (the reference's csa table, fmidx.c:153-163) and locates the
+@pytest.mark.parametrize("ratio", [4, 32])
+def test_sampled_sa_locate_mode(gpu, name, ratio):
+    """lrm_index_options.sa_sampled = r keeps SA rows i*r only (the reference's csa table, fmidx.c:153-163) and locates the
     rest by LF steps on the device (csa_access, fmidx.c:315-331, with the textbook LF -- see seed_kernels.hip):
     identical best[] to the full-SA mode and to the oracle, with 1/r of the SA bytes in HBM."""
     sc = workloads.scenario(name)
     oi = orc.OracleIndex.from_host_index(sc["hi"])
     want, _ = oi.seed_batch(sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
     full = sc["hi"].blob_bytes()
-    monkeypatch.setenv("LRM_SA_SAMPLED", ratio)
-    assert sc["hi"].blob_bytes() < full
-    di = index.DeviceIndex.upload(sc["hi"], gpu)
-    monkeypatch.delenv("LRM_SA_SAMPLED")
+    assert sc["hi"].blob_bytes(sa_sampled=ratio) < full
+    di = index.DeviceIndex.upload(sc["hi"], gpu, sa_sampled=ratio)
     try:
         got = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
         assert np.array_equal(got, want)
@@ -204,12 +260,7 @@ def test_suffix_array_values_beyond_32_bits(gpu):
     finally:
         di.close()
     # the same through the sampled-SA mode (values are added to LF step counts after the gather)
-    import os
-    os.environ["LRM_SA_SAMPLED"] = "4"
-    try:
-        di = index.DeviceIndex.upload(hi, gpu)
-    finally:
-        del os.environ["LRM_SA_SAMPLED"]
+    di = index.DeviceIndex.upload(hi, gpu, sa_sampled=4)
     try:
         # sampled rows hold shifted values; unsampled rows add their step count: still the shifted SA
         got = mapper.seed_batch(di, r["reads"], r["lens"], 20, 300)

@@ -68,11 +68,11 @@ def test_ultralong_100k_byte_kernels(ref3, T, O, W):
 
 
 @pytest.mark.parametrize("T,O,W", [(320, 120, 128), (512, 64, 64)])
-def test_ultralong_100k_bitsliced(ref3, monkeypatch, T, O, W):
+def test_ultralong_100k_bitsliced(ref3, map_options, T, O, W):
     """The W <= 128 points of the config-4 sweep through the lane-per-read kernel (500 tiles per read), reads of
     100 kbp next to short ones so that lanes finish at very different times."""
-    monkeypatch.setenv("LRM_GACT_IMPL", "4")
     seqs, hi, di, oi = ref3
+    map_options(di, gact_impl=4)
     r = synth.reads(seqs, 6, 100_000, synth.ONT, seed=17)
     lens = r["lens"].copy()
     lens[1], lens[4] = 7_000, 333
@@ -95,7 +95,7 @@ def ultralong(ref3):
 
 
 @pytest.mark.parametrize("T,O,W", SWEEP, ids=["T%d-O%d-W%d" % p for p in SWEEP])
-def test_config5_full_gact_sweep(ref3, ultralong, monkeypatch, T, O, W):
+def test_config5_full_gact_sweep(ref3, ultralong, map_options, T, O, W):
     """every point of T in {128,256,320,512} x O in {32,64,120} x W in {32,64,128,T} on
     100 kbp reads (45 distinct points: W = T coincides with 128 for T = 128).  W <= 128 runs on the bit-sliced
     lane-per-read kernel (what large batches use), W > 128 on the wide-band kernel; extension results are
@@ -103,7 +103,7 @@ def test_config5_full_gact_sweep(ref3, ultralong, monkeypatch, T, O, W):
     seqs, hi, di, oi = ref3
     reads, lens, best = ultralong
     if W <= 128:
-        monkeypatch.setenv("LRM_GACT_IMPL", "4")
+        map_options(di, gact_impl=4)
     rc, rg = reads.copy(), reads.copy()
     want = oi.extend_batch(rc, lens, best, (T, O, W), nthreads=8)
     got = mapper.extend_batch(di, rg, lens, best, (T, O, W))
@@ -115,9 +115,9 @@ def test_config5_full_gact_sweep(ref3, ultralong, monkeypatch, T, O, W):
     assert (want["score"] >= 0).all()
 
 
-def test_pacbio_and_multiseq_bitsliced(ref3, monkeypatch):
-    monkeypatch.setenv("LRM_GACT_IMPL", "4")
+def test_pacbio_and_multiseq_bitsliced(ref3, map_options):
     seqs, hi, di, oi = ref3
+    map_options(di, gact_impl=4)
     r = synth.reads(seqs, 48, 15_000, synth.PACBIO_CLR, seed=13)
     _compare(di, oi, r["reads"], r["lens"], (320, 120, 128))
     r = synth.reads(seqs, 64, 10_000, synth.ONT, seed=11)
@@ -131,16 +131,16 @@ def test_largest_tile_and_band(ref3):
     _compare(di, oi, r["reads"], r["lens"], (512, 0, 1024))
 
 
-@pytest.mark.parametrize("alphabet,impl", [(b"ACGTacgtNRY-", None), (b"ACGTacgtNRY-", "4"), (b"ACGT", "4")])
-def test_revcomp_in_place_ragged_rows(ref3, monkeypatch, alphabet, impl):
+@pytest.mark.parametrize("alphabet,impl", [(b"ACGTacgtNRY-", None), (b"ACGTacgtNRY-", 4), (b"ACGT", 4)])
+def test_revcomp_in_place_ragged_rows(ref3, map_options, alphabet, impl):
     """`_rev_comp_in_place` (alnmain.c:27-60) on rows of every alignment: lengths 1..70, around the kernel's
     4096-base span boundaries, odd and even, with lower-case and non-ACGT bytes (-> 'N'), every read placed on the
-    reverse strand by its locus; forward-strand rows in between must stay untouched.  With LRM_GACT_IMPL=4 the same
+    reverse strand by its locus; forward-strand rows in between must stay untouched.  With gact_impl = 4 the same
     rows also go through the planar packer of the bit-sliced kernel (16 bases per lane from unaligned rows; reads with
     a byte other than ACGT are flagged there and fall back to the byte kernel)."""
-    if impl:
-        monkeypatch.setenv("LRM_GACT_IMPL", impl)
     seqs, hi, di, oi = ref3
+    if impl:
+        map_options(di, gact_impl=impl)
     lens = list(range(1, 71)) + [4095, 4096, 4097, 8191, 8192, 8193, 8223, 8224, 8225, 12289, 16384, 16399, 20001]
     n, mx = len(lens), max(lens)
     rng = np.random.default_rng(5)

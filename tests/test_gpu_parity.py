@@ -26,13 +26,13 @@ def dev_indexes(gpu):
         di.close()
 
 
-def _gpu_gact(q, d, T, O, W):
+def _gpu_gact(q, d, T, O, W, impl=0):
     qa = np.frombuffer(q, dtype=np.uint8)
     da = np.frombuffer(d, dtype=np.uint8)
     ops = np.zeros(len(q) + len(d) + 16, dtype=np.uint8)
     n_ops, score = C.c_int(), C.c_int()
-    capi.check(capi.lib.lrm_debug_gact(qa.ctypes.data, len(q), da.ctypes.data, len(d), capi.GactParams(T, O, W),
-                                       ops.ctypes.data, C.byref(n_ops), C.byref(score), 0), "lrm_debug_gact")
+    capi.check(capi.lib.lrm_debug_gact_impl(qa.ctypes.data, len(q), da.ctypes.data, len(d), capi.GactParams(T, O, W), impl,
+                                            ops.ctypes.data, C.byref(n_ops), C.byref(score), 0), "lrm_debug_gact_impl")
     return score.value, bytes(ops[:n_ops.value])
 
 
@@ -83,9 +83,8 @@ BS_PARAMS = [(320, 120, 128), (512, 120, 128), (100, 99, 128), (320, 0, 128), (6
 
 
 @pytest.mark.parametrize("T,O,W", BS_PARAMS)
-def test_gact_bitsliced_kernel_vs_oracle(gpu, monkeypatch, T, O, W):
-    """LRM_GACT_IMPL=4: the lane-per-read bit-sliced kernel (normally used for batches >= 16 k reads)."""
-    monkeypatch.setenv("LRM_GACT_IMPL", "4")
+def test_gact_bitsliced_kernel_vs_oracle(gpu, T, O, W):
+    """gact_impl = 4: the lane-per-read bit-sliced kernel (normally used for batches >= 16 k reads)."""
     rng = np.random.default_rng(T * 1000 + O * 10 + 7)
     ref = bytes(synth.reference(20000, seed=3))
     sizes = [1, 2, 5, 31, 63, 64, 65, 127, 199, 200, 201, 319, 320, 321, 500, 1000, 2500]
@@ -98,12 +97,12 @@ def test_gact_bitsliced_kernel_vs_oracle(gpu, monkeypatch, T, O, W):
             for m in {len(q), max(1, len(q) - 7), len(q) + 13}:
                 d = ref[p:p + m]
                 want = orc.gact(q, d, T, O, W)
-                got = _gpu_gact(q, d, T, O, W)
+                got = _gpu_gact(q, d, T, O, W, 4)
                 assert got == (want[0], want[1]), (n, prof, m)
     q, d = ref[100:700], ref[9000:9600]
-    assert _gpu_gact(q, d, T, O, W) == orc.gact(q, d, T, O, W)[:2]
+    assert _gpu_gact(q, d, T, O, W, 4) == orc.gact(q, d, T, O, W)[:2]
     q, d = ref[140:900], ref[100:860]
-    assert _gpu_gact(q, d, T, O, W) == orc.gact(q, d, T, O, W)[:2]
+    assert _gpu_gact(q, d, T, O, W, 4) == orc.gact(q, d, T, O, W)[:2]
     # a byte other than ACGT in the read or in the text: routed to the byte kernel, same answer
     q, d = bytearray(ref[300:1300]), bytearray(ref[300:1300])
     q[500] = ord("N")
@@ -125,8 +124,8 @@ def test_gact_rejects_unsupported_params(gpu):
 @pytest.mark.parametrize("long_table", ["0", "auto", "16", "13-plain", "14"])
 @pytest.mark.parametrize("name", ["clean-1k", "ont-2k", "pacbio-3k-h12", "ragged", "seed12", "seed32",
                                   "seed-below-hlen", "repeats-ties"])
-def test_seed_search_per_seed(dev_indexes, gpu, monkeypatch, name, long_table):
-    """K1 alone: (j, rr, k, l) of every seed of a read.  With LRM_LC_LONG=0 (the reference's table only) also the
+def test_seed_search_per_seed(dev_indexes, gpu, name, long_table):
+    """K1 alone: (j, rr, k, l) of every seed of a read.  With lc_long = 0 (the reference's table only) also the
     k > l pairs of failed searches are the reference's (fmidx.c:310-312); through the long seed table (automatic:
     pair-line 16-mers when 128 GiB of HBM are free, shorter k-mers otherwise; "13-plain": the plain layout) a seed that
     dies inside its last hl bases reports k = l = 0 -- rr = 0 either way, and the reference never reads k, l of such
@@ -136,10 +135,8 @@ def test_seed_search_per_seed(dev_indexes, gpu, monkeypatch, name, long_table):
     sc, di, oi = dev_indexes(name)
     own = None
     if long_table != "auto":
-        monkeypatch.setenv("LRM_LC_LONG", long_table.split("-")[0])
-        if long_table.endswith("-plain"):
-            monkeypatch.setenv("LRM_LC_PAIR", "0")
-        own = di = index.DeviceIndex.upload(sc["hi"], gpu)
+        own = di = index.DeviceIndex.upload(sc["hi"], gpu, lc_long=int(long_table.split("-")[0]),
+                                            lc_pair=0 if long_table.endswith("-plain") else None)
     s = sc["seed_len"]
     for i in range(0, len(sc["lens"]), 5):
         ln = int(sc["lens"][i])
@@ -170,15 +167,14 @@ def test_seed_search_per_seed(dev_indexes, gpu, monkeypatch, name, long_table):
 
 
 @pytest.mark.parametrize("name", workloads.SEED_SCENARIOS)
-def test_seed_batch_vs_oracle(dev_indexes, gpu, monkeypatch, name):
+def test_seed_batch_vs_oracle(dev_indexes, gpu, name):
     sc, di, oi = dev_indexes(name)
     want, phases = oi.seed_batch(sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
     got = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
     for f in ("key", "val", "bucket"):
         assert np.array_equal(got[f], want[f]), (name, f, np.nonzero(got[f] != want[f])[0][:10])
     # the same through the long seed table (what large texts use automatically)
-    monkeypatch.setenv("LRM_LC_LONG", "14")
-    d2 = index.DeviceIndex.upload(sc["hi"], gpu)
+    d2 = index.DeviceIndex.upload(sc["hi"], gpu, lc_long=14)
     got = mapper.seed_batch(d2, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
     d2.close()
     for f in ("key", "val", "bucket"):
@@ -208,11 +204,11 @@ def test_vote_tiers_beyond_the_wave_table(dev_indexes, gpu):
 
 @pytest.mark.parametrize("name", ["clean-1k", "ont-2k", "pacbio-3k-h12", "ragged", "repeats-ties"])
 @pytest.mark.parametrize("gact", [(320, 120, 128), (128, 64, 32), (320, 120, 128, "bitsliced")])
-def test_extend_batch_vs_oracle(dev_indexes, monkeypatch, name, gact):
-    if len(gact) == 4:
-        monkeypatch.setenv("LRM_GACT_IMPL", "4")
-        gact = gact[:3]
+def test_extend_batch_vs_oracle(dev_indexes, map_options, name, gact):
     sc, di, oi = dev_indexes(name)
+    if len(gact) == 4:
+        map_options(di, gact_impl=4)
+        gact = gact[:3]
     best, _ = oi.seed_batch(sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
     if name == "ragged":     # also: a wrapped diagonal, a locus straddling the strand boundary, the last bases
         best = best.copy()
@@ -264,12 +260,12 @@ def test_device_resident_pipeline_equals_host_path(dev_indexes, gpu):
 
 
 @pytest.mark.parametrize("name", ["ont-2k", "ragged"])
-def test_bitsliced_kernel_is_the_one_that_runs(dev_indexes, gpu, monkeypatch, name):
-    """Device-resident extend with LRM_GACT_IMPL=4: the launch record must show gact_bs_kernel (no silent
+def test_bitsliced_kernel_is_the_one_that_runs(dev_indexes, gpu, map_options, name):
+    """Device-resident extend with gact_impl = 4: the launch record must show gact_bs_kernel (no silent
     route through the byte kernels), results equal the oracle's; one read carries an N (byte kernel, flagged)."""
     import torch
-    monkeypatch.setenv("LRM_GACT_IMPL", "4")
     sc, di, oi = dev_indexes(name)
+    map_options(di, gact_impl=4)
     reads = sc["reads"].copy()
     n, stride = reads.shape
     dm = mapper.DeviceMapper(di, n, stride - 1, sc["seed_len"], sc["thres"], device=gpu)
@@ -297,13 +293,12 @@ def test_bitsliced_kernel_is_the_one_that_runs(dev_indexes, gpu, monkeypatch, na
     dm.close()
 
 
-@pytest.mark.parametrize("waves", ["1", "2"])
-def test_bitsliced_lane_refill(dev_indexes, monkeypatch, waves):
-    """LRM_BS_WAVES: a grid of one or two wavefronts for 230 reads of very different lengths -- every lane takes
+@pytest.mark.parametrize("waves", [1, 2])
+def test_bitsliced_lane_refill(dev_indexes, map_options, waves):
+    """lrm_map_options.bs_waves: a grid of one or two wavefronts for 230 reads of very different lengths -- every lane takes
     several reads from the queue in turn (what happens to every batch above 131 k reads), next to fenced reads."""
-    monkeypatch.setenv("LRM_GACT_IMPL", "4")
-    monkeypatch.setenv("LRM_BS_WAVES", waves)
     sc, di, oi = dev_indexes("ont-2k")
+    map_options(di, gact_impl=4, bs_waves=waves)
     rng = np.random.default_rng(5)
     n0, stride = sc["reads"].shape
     n = 230
@@ -331,22 +326,20 @@ def test_bitsliced_lane_refill(dev_indexes, monkeypatch, waves):
     assert np.array_equal(r_gpu, r_cpu)
 
 
-def test_host_batches_are_sliced_without_changing_results(dev_indexes, monkeypatch):
-    """Caller batches above ~32 GB of device scratch go through the device in slices (LRM_HOST_SLICE forces 7 reads
+def test_host_batches_are_sliced_without_changing_results(dev_indexes, map_options):
+    """Caller batches above ~32 GB of device scratch go through the device in slices (slice_reads forces 7 reads
     per slice here): same best[], scores, ops, rev-comped reads as in one pass."""
     sc, di, oi = dev_indexes("ont-2k")
     best = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
     r1 = sc["reads"].copy()
     e1 = mapper.extend_batch(di, r1, sc["lens"], best)
     # slices of 7 reads; then one slice cut into 5 pipelined sub-batches (upload k+1 / kernels k / download k-1)
-    for env in ({"LRM_HOST_SLICE": "7"}, {"LRM_HOST_SUBS": "5"}, {"LRM_HOST_SLICE": "23", "LRM_HOST_SUBS": "2"}):
-        for k_, v_ in env.items():
-            monkeypatch.setenv(k_, v_)
+    for env in ({"slice_reads": 7}, {"sub_batches": 5}, {"slice_reads": 23, "sub_batches": 2}):
+        map_options(di, **env)
         best2 = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
         r2 = sc["reads"].copy()
         e2 = mapper.extend_batch(di, r2, sc["lens"], best2)
-        for k_ in env:
-            monkeypatch.delenv(k_)
+        map_options(di)
         assert np.array_equal(best, best2) and np.array_equal(r1, r2), env
         assert np.array_equal(e1["score"], e2["score"]) and np.array_equal(e1["n_ops"], e2["n_ops"]), env
         for i in range(len(best)):
@@ -370,31 +363,29 @@ def test_blob_roundtrip_and_adopt(dev_indexes, gpu):
 
 
 
-def test_long_interval_side_table(gpu, monkeypatch):
+def test_long_interval_side_table(gpu):
     """lchash intervals too long for the 24-bit count of the 8-byte device entries go through a sorted
     side table; the packer's threshold knob sends ordinary repeats there so the path is exercised."""
     sc = workloads.scenario("repeats-ties")
     oi = orc.OracleIndex.from_host_index(sc["hi"])
     want, _ = oi.seed_batch(sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
-    monkeypatch.setenv("LRM_LCX_THRESHOLD", "30")
-    di = index.DeviceIndex.upload(sc["hi"], gpu)
-    monkeypatch.delenv("LRM_LCX_THRESHOLD")
+    di = index.DeviceIndex.upload(sc["hi"], gpu, lcx_threshold=30)
     got = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
     assert np.array_equal(got, want)
     di.close()
 
 
 @pytest.mark.parametrize("name", ["clean-1k", "ont-2k", "last-phase-break", "ragged"])
-def test_round_policy_does_not_change_results(dev_indexes, monkeypatch, name):
+def test_round_policy_does_not_change_results(dev_indexes, map_options, name):
     """Phase 0 first and phases 1..s for the undecided reads (two rounds), or all phases at once (what the library
     switches to when the previous batch decided almost nothing in phase 0): same best[], because evaluating phases
     speculatively and replaying alnmain.c:371-403 in order is exact."""
     sc, di, oi = dev_indexes(name)
     want, _ = oi.seed_batch(sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
-    for rounds in ("2", "1", "2"):
-        monkeypatch.setenv("LRM_SEED_ROUNDS", rounds)
+    for rounds in (2, 1, 2):
+        map_options(di, seed_rounds=rounds)
         got = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
         assert np.array_equal(got, want), (name, rounds)
-    monkeypatch.delenv("LRM_SEED_ROUNDS")
+    map_options(di)
     for _ in range(3):                     # the adaptive policy: the second and third call see the first one's history
         assert np.array_equal(mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"]), want)

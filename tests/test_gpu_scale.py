@@ -84,7 +84,7 @@ def test_oracle_spot_check(world):
         assert bytes(want["ops"][n, :k]) == bytes(world["ext"]["ops"][i, :k])
 
 
-def test_bitsliced_and_score_kernels_agree_at_batch_scale(world, monkeypatch):
+def test_bitsliced_and_score_kernels_agree_at_batch_scale(world, map_options):
     """20 k reads: above the automatic switch to the lane-per-read bit-sliced kernel.  Its CIGARs must equal the
     score kernel's for every read (two independent formulations of docs/GACT_SPEC.md), and the oracle's on a few."""
     di = world["di"]
@@ -92,7 +92,7 @@ def test_bitsliced_and_score_kernels_agree_at_batch_scale(world, monkeypatch):
     best = mapper.seed_batch(di, r["reads"], r["lens"])
     ra = r["reads"].copy()
     a = mapper.extend_batch(di, ra, r["lens"], best)                 # automatic: bit-sliced at this size
-    monkeypatch.setenv("LRM_GACT_IMPL", "3")
+    map_options(di, gact_impl=3)
     rb = r["reads"].copy()
     b = mapper.extend_batch(di, rb, r["lens"], best)
     assert np.array_equal(ra, rb)

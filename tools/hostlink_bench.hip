@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <omp.h>
 #include <sys/resource.h>
+#include <unistd.h>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -137,14 +138,20 @@ int main(int argc, char **argv) {
         hipEvent_t e_spin, e_block;
         CHECK(hipEventCreateWithFlags(&e_spin, hipEventDisableTiming));
         CHECK(hipEventCreateWithFlags(&e_block, hipEventBlockingSync | hipEventDisableTiming));
-        for (int mode = 0; mode < 3; ++mode) {
+        for (int mode = 0; mode < 4; ++mode) {
             hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s1, cyc, (uint64_t *) nullptr);
             const double c0 = cpu_s(), t0 = now();
             if (mode == 0) { CHECK(hipEventRecord(e_spin, s1)); CHECK(hipEventSynchronize(e_spin)); }
             else if (mode == 1) { CHECK(hipEventRecord(e_block, s1)); CHECK(hipEventSynchronize(e_block)); }
-            else CHECK(hipStreamSynchronize(s1));
+            else if (mode == 2) CHECK(hipStreamSynchronize(s1));
+            else {                                               // what lrm_host.hip does: query, sleep 20..200 us, query
+                CHECK(hipEventRecord(e_spin, s1));
+                useconds_t nap = 20;
+                while (hipEventQuery(e_spin) == hipErrorNotReady) { (void) hipGetLastError(); usleep(nap); if (nap < 200) nap += 20; }
+            }
             printf("{\"test\": \"wait for a 200 ms kernel\", \"how\": \"%s\", \"wall_ms\": %.1f, \"cpu_ms\": %.1f}\n",
-                   mode == 0 ? "hipEventSynchronize, default event" : mode == 1 ? "hipEventSynchronize, hipEventBlockingSync event" : "hipStreamSynchronize",
+                   mode == 0 ? "hipEventSynchronize, default event" : mode == 1 ? "hipEventSynchronize, hipEventBlockingSync event" :
+                   mode == 2 ? "hipStreamSynchronize" : "hipEventQuery + usleep(20..200 us)",
                    (now() - t0) * 1e3, (cpu_s() - c0) * 1e3);
             fflush(stdout);
         }

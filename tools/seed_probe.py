@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from longreadmapper_amd import index, mapper, synth
+from longreadmapper_amd import capi, index, mapper, synth
 
 n, Lr = int(os.environ.get("PROBE_READS", "100000")), int(os.environ.get("PROBE_LEN", "10000"))
 ref = synth.reference(int(os.environ.get("PROBE_REF", "4641652")), seed=1, repeat_frac=0.05, rep_len=300, rep_copies=1000, rep_div=0.05)
@@ -22,6 +22,7 @@ base = None
 for var in (sys.argv[1:] or [""]):
     kv = dict(x.split("=") for x in var.split()) if var else {}
     os.environ.update(kv)
+    capi.lib.lrm_debug_reload_env(di.handle)           # the overrides are normally read once per handle
     dm.seed(d_reads, d_lens)
     torch.cuda.synchronize()
     dm.set_timing(True)
