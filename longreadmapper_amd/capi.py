@@ -66,7 +66,7 @@ class IndexOptions(C.Structure):       # lrm_index_options
 
 class MapOptions(C.Structure):         # lrm_map_options
     _fields_ = [("struct_size", C.c_uint32), ("dense_results", C.c_int32), ("gact_impl", C.c_int32),
-                ("seed_rounds", C.c_int32), ("direct_rows", C.c_int32), ("slice_reads", C.c_uint32),
+                ("seed_rounds", C.c_int32), ("reserved0", C.c_int32), ("slice_reads", C.c_uint32),
                 ("sub_batches", C.c_uint32), ("group_subs", C.c_uint32), ("bs_waves", C.c_uint32),
                 ("reserved", C.c_uint32 * 10)]
 

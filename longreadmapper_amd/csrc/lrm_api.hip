@@ -69,9 +69,9 @@ static inline uint64_t align256(uint64_t x) { return (x + 255ull) & ~255ull; }
 // ------------------------------------------------------------------------------------------
 static const char *const k_env_names[] = {
     "LRM_SA_SAMPLED", "LRM_LC_LONG", "LRM_LC_PAIR", "LRM_LCX_THRESHOLD",                         // index
-    "LRM_GACT_IMPL", "LRM_SEED_ROUNDS", "LRM_HOST_DENSE", "LRM_HOST_DIRECT", "LRM_HOST_SLICE", "LRM_HOST_SUBS",
+    "LRM_GACT_IMPL", "LRM_SEED_ROUNDS", "LRM_HOST_DENSE", "LRM_HOST_SLICE", "LRM_HOST_SUBS",
     "LRM_HOST_GROUP", "LRM_BS_WAVES", "LRM_SS_ITEMS", "LRM_VOTE_VG", "LRM_VOTE_T1", "LRM_VOTE_U", "LRM_VOTE_LOAD",
-    "LRM_HOST_EXT_STREAMS", "LRM_HOST_SEED_STREAMS", "LRM_HOST_VERBOSE", "LRM_VOTE_SORT"};
+    "LRM_HOST_EXT_STREAMS", "LRM_HOST_SEED_STREAMS", "LRM_HOST_VERBOSE", "LRM_VOTE_SORT", "LRM_HOST_SLOTS"};
 static_assert(sizeof(k_env_names) / sizeof(k_env_names[0]) <= LrmEnv::MAXV, "LrmEnv too small");
 
 void lrm_env_snapshot(LrmEnv *e) {
@@ -99,7 +99,6 @@ extern "C" void lrm_map_options_init(lrm_map_options *o) {
     if (!o) return;
     memset(o, 0, sizeof(*o));
     o->struct_size = (uint32_t) sizeof(*o);
-    o->direct_rows = -1;
 }
 
 static inline bool valid_sa_ratio(long long r) { return r >= 2 && r <= 64 && (r & (r - 1)) == 0; }
@@ -127,7 +126,7 @@ void lrm_resolve_map_tune(const lrm_map_options *opt, const LrmEnv &env, LrmMapT
     if (opt) memcpy(&o, opt, opt->struct_size && opt->struct_size < sizeof(o) ? opt->struct_size : sizeof(o));
     memset(t, 0, sizeof(*t));
     t->dense = o.dense_results != 0;
-    t->gact_impl = o.gact_impl; t->seed_rounds = o.seed_rounds; t->direct_rows = o.direct_rows;
+    t->gact_impl = o.gact_impl; t->seed_rounds = o.seed_rounds;
     t->slice_reads = o.slice_reads; t->sub_batches = o.sub_batches; t->group_subs = o.group_subs; t->bs_waves = o.bs_waves;
     // measured defaults of the kernel knobs (tools/seed_probe.py sweeps them through the environment)
     t->ss_items = 2048; t->vote_vg = 16; t->vote_t1 = LRM_VOTE_T1_LIMIT; t->vote_u = 2; t->vote_load = 50;
@@ -136,7 +135,6 @@ void lrm_resolve_map_tune(const lrm_map_options *opt, const LrmEnv &env, LrmMapT
     if (env.get("LRM_GACT_IMPL", &v)) t->gact_impl = (int) v;
     if (env.get("LRM_SEED_ROUNDS", &v)) t->seed_rounds = (int) v;
     if (env.get("LRM_HOST_DENSE", &v)) t->dense = v != 0;
-    if (env.get("LRM_HOST_DIRECT", &v)) t->direct_rows = v != 0;
     if (env.get("LRM_HOST_SLICE", &v) && v >= 1) t->slice_reads = (uint32_t) v;
     if (env.get("LRM_HOST_SUBS", &v) && v >= 1) t->sub_batches = (uint32_t) v;
     if (env.get("LRM_HOST_GROUP", &v) && v >= 1) t->group_subs = (uint32_t) v;

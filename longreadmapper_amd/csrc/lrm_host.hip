@@ -17,19 +17,18 @@
 // With two slots the upload and the seeds of batch k+1 run under the extension tail and the result download of
 // batch k -- the serial chain that bounds a single call.  Stream priorities: results > extension > seeds.
 //
-// How results reach the caller (lrm_map_options):
-//   dense_results   the used op bytes of a group are packed back to back on the device and cross the link as ONE DMA
-//                   straight into the caller's (pinned) store_mem; cig[i].cigar points into it.  No host copy at all.
-//   rows (default)  cig[i].cigar = store_mem + i*store_stride as in alnmain.c:322-325.  With pinned caller buffers the
-//                   device writes the rows into the caller's memory itself (direct_rows; posted writes at the link
-//                   rate, tools/hostlink_bench.hip), else the dense image comes down through pinned chunks and a small
-//                   memcpy team scatters it.
-// The reverse-complemented reads always have to land in strided caller rows: device row writes when reads_buf is
-// pinned, dense DMA + scatter otherwise.
+// How results reach the caller (lrm_map_options): always as a DENSE image packed on the device (the used part of every
+// CIGAR row, the reverse-complemented reads) that crosses the link by DMA at its full rate -- a strided hipMemcpy2D of
+// the same rows does 6 GB/s, and a kernel writing the caller's pinned memory itself collapses to 2-9 GB/s as soon as
+// compute kernels own the chip (tools/d2h_under_load.hip).
+//   dense_results   the op bytes stay dense: ONE DMA per group straight into the caller's (pinned) store_mem, and
+//                   cig[i].cigar points into it (the convention of mutils.c:97-103 kept).  The reverse-complemented
+//                   reads are the only rows left to place: through a ring of pinned chunks, by the collector alone.
+//   rows (default)  cig[i].cigar = store_mem + i*store_stride as in alnmain.c:322-325: the whole image comes down
+//                   through the ring and a small memcpy team scatters it.
 //
 // Host CPU: every wait for the device is a sleep-poll on an event (hipEventSynchronize and hipStreamSynchronize spin
-// a core for the whole wait on this platform, blocking-sync events included: tools/hostlink_bench.hip), and with
-// pinned buffers no thread of the library touches a payload byte.
+// a core for the whole wait on this platform, blocking-sync events included: tools/hostlink_bench.hip).
 // No CPU fallback: without a HIP device every entry point fails.
 #include <hip/hip_runtime.h>
 #include <unistd.h>
@@ -100,10 +99,12 @@ struct PinSlot {
     void release() { if (p) (void) hipHostFree(p); p = nullptr; cap = 0; }
 };
 
-constexpr uint64_t STAGE_CHUNK = 32ull << 20;
+constexpr uint64_t STAGE_CHUNK = 32ull << 20;      // pinned chunks of the pageable upload staging
+constexpr uint64_t RING_CHUNK = 16ull << 20;       // ... and of the download ring
+constexpr int N_RING = 4;
 constexpr int N_SEED_STREAMS = 3;
 constexpr int N_EXT_STREAMS = 4;
-constexpr int N_SLOTS = 2;            // batches (slices) in flight per replica
+constexpr int N_SLOTS = 3;            // upper bound on the batches (slices) in flight per replica; n_slots of them are used
 struct DevSet { DevSlot reads, lens, best, store, nops, score, meta, mr; };
 
 // device-side resources of one slice in flight
@@ -141,6 +142,7 @@ struct SliceJob;
 struct LrmHostCtx {
     lrm_index *idx = nullptr;
     int copy_threads = 4;                // memcpy team of the pageable paths (staging upload, result scatter)
+    int n_slots = 2;                     // slices in flight (LRM_HOST_SLOTS)
     // --- queues (mu) ---
     std::mutex mu;
     std::condition_variable cv;
@@ -158,8 +160,8 @@ struct LrmHostCtx {
     bool pin_up_used[2] = {false, false};
     uint64_t up_seq = 0;
     // collector only: chunks of the scatter path, event of the small copies
-    void *pin_dn[2] = {nullptr, nullptr};
-    hipEvent_t ev_pin_dn[2] = {nullptr, nullptr};
+    void *pin_dn[N_RING] = {};
+    hipEvent_t ev_pin_dn[N_RING] = {};
     hipEvent_t ev_small = nullptr, ev_tail = nullptr;
     bool ready = false;
 };
@@ -175,10 +177,13 @@ hipEvent_t new_event() {
 int ctx_init(LrmHostCtx &c) {
     if (c.ready) return 0;
     for (int b = 0; b < 2; ++b) {
-        if (hipHostMalloc(&c.pin_up[b], STAGE_CHUNK, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc(&c.pin_dn[b], STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) { lrm_set_error("pinned staging allocation failed"); return -1; }
-        if (!(c.ev_pin_up[b] = new_event()) || !(c.ev_pin_dn[b] = new_event())) { lrm_set_error("event creation failed"); return -1; }
+        if (hipHostMalloc(&c.pin_up[b], STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) { lrm_set_error("pinned staging allocation failed"); return -1; }
+        if (!(c.ev_pin_up[b] = new_event())) { lrm_set_error("event creation failed"); return -1; }
         for (int s = 0; s < N_SLOTS; ++s) if (!(c.slots[s].ev_dense[b] = new_event())) { lrm_set_error("event creation failed"); return -1; }
+    }
+    for (int b = 0; b < N_RING; ++b) {
+        if (hipHostMalloc(&c.pin_dn[b], RING_CHUNK, hipHostMallocDefault) != hipSuccess) { lrm_set_error("pinned staging allocation failed"); return -1; }
+        if (!(c.ev_pin_dn[b] = new_event())) { lrm_set_error("event creation failed"); return -1; }
     }
     if (!(c.ev_small = new_event()) || !(c.ev_tail = new_event())) { lrm_set_error("event creation failed"); return -1; }
     // Priorities: the result path first (pack kernels + downloads), then the extension of a finished group, then
@@ -261,64 +266,51 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t *__restric
     }
 }
 
-// rows of a pitched device array -> rows of another pitched array (len[i] bytes of row i; 0 = skip).  The
-// destination may be the device alias of PINNED HOST memory: the stores then cross the link as posted writes,
-// 1 KiB per wavefront instruction, and the caller's rows are filled with no staging copy and no host work
-// (54 GB/s on its own, the link's rate shared with a concurrent DMA: tools/hostlink_bench.hip).
-__global__ __launch_bounds__(256) void copy_rows_kernel(const uint8_t *__restrict__ src, uint64_t spitch,
-                                                        uint8_t *__restrict__ dst, uint64_t dpitch,
-                                                        const uint32_t *__restrict__ len, uint64_t rows) {
-    const uint64_t row = blockIdx.x;
-    if (row >= rows) return;
-    const uint32_t l = len[row];
-    const uint8_t *s = src + row * spitch;
-    uint8_t *d = dst + row * dpitch;
-    const uint32_t head = (uint32_t) ((16u - ((uintptr_t) d & 15u)) & 15u);         // bytes up to the first aligned 16
-    if (blockIdx.y == 0) for (uint32_t o = threadIdx.x; o < head && o < l; o += 256) d[o] = s[o];
-    for (uint32_t o = head + (blockIdx.y * 256 + threadIdx.x) * 16; o < l; o += gridDim.y * 256 * 16) {
-        if (o + 16 <= l) {
-            uint32_t w[4];
-            __builtin_memcpy(w, s + o, 16);
-            *reinterpret_cast<uint4 *>(d + o) = make_uint4(w[0], w[1], w[2], w[3]);
-        } else {
-            for (uint32_t e = 0; o + e < l; ++e) d[o + e] = s[o + e];
-        }
-    }
-}
-
-// dense device buffer -> rows of the caller's arrays (the pageable / row-layout path): contiguous DMA through the
-// context's pinned chunks, every chunk scattered into the caller's rows by a small memcpy team while the next one flies.
-// off[i] (16-byte aligned, ascending) / len[i]: position and length of entry i in the dense buffer; dst[i]: where
-// its bytes go.
-int d2h_scatter(LrmHostCtx &c, const uint8_t *d_dense, uint64_t total, const uint64_t *off, const uint32_t *len,
-                uint8_t *const *dst, uint64_t rows) {
-    if (total == 0) return 0;
-    uint64_t k = 0, o = 0, prev_o = 0, prev_l = 0;
-    uint64_t row_lo = 0;                                              // first entry that may still have bytes at or after prev_o
-    while (true) {
-        const int b = (int) (k & 1);
-        const uint64_t l = o < total ? (total - o < STAGE_CHUNK ? total - o : STAGE_CHUNK) : 0;
-        if (l) {
+// dense device buffer -> the caller's memory through the context's ring of pinned chunks: contiguous DMA pieces, every
+// piece copied into place while the next ones fly.  Entries i with off[i] (16-byte aligned, ascending) / len[i] in the
+// dense buffer go to dst[i]; dst == nullptr: the image is copied as it is to `flat`.
+// `threads` = 1: the collector copies alone with plain memcpy -- no OpenMP team, whose idle threads spin between the
+// pieces (8 threads spinning through every download was 0.35 CPU-s per Gbp); the row layout of the op bytes (1.1 GB per
+// Gbp to scatter) needs the team.
+// `after_issue` runs once, as soon as the last piece has been handed to the DMA engine (before the ring is drained):
+// whatever it queues flies while this thread still copies.
+template <typename F>
+int d2h_ring(LrmHostCtx &c, const uint8_t *d_dense, uint64_t total, const uint64_t *off, const uint32_t *len,
+             uint8_t *const *dst, uint64_t rows, uint8_t *flat, int threads, F after_issue) {
+    if (total == 0) return after_issue();
+    const uint64_t np = (total + RING_CHUNK - 1) / RING_CHUNK;
+    uint64_t row_lo = 0;                                              // first entry that may still have bytes at or after the piece
+    for (uint64_t k = 0; k < np + N_RING - 1; ++k) {
+        if (k < np) {                                                 // issue piece k (its chunk was drained N_RING pieces ago)
+            const int b = (int) (k % N_RING);
+            const uint64_t o = k * RING_CHUNK, l = total - o < RING_CHUNK ? total - o : RING_CHUNK;
             HIPCHK(hipMemcpyAsync(c.pin_dn[b], d_dense + o, l, hipMemcpyDeviceToHost, c.down));
             HIPCHK(hipEventRecord(c.ev_pin_dn[b], c.down));
+            if (k + 1 == np && after_issue()) return -1;
         }
-        if (prev_l) {                                                 // scatter the previous chunk while this one flies
-            const int pb = (int) ((k - 1) & 1);
-            if (wait_event(c.ev_pin_dn[pb])) return -1;
-            const uint8_t *chunk = (const uint8_t *) c.pin_dn[pb];
-            const uint64_t c0 = prev_o, c1 = prev_o + prev_l;
-            while (row_lo < rows && off[row_lo] + len[row_lo] <= c0) ++row_lo;
-            uint64_t row_hi = row_lo;
-            while (row_hi < rows && off[row_hi] < c1) ++row_hi;
-            const int nt = c.copy_threads;
-#pragma omp parallel for schedule(static) num_threads(nt)
+        if (k + 1 < N_RING) continue;
+        const uint64_t p = k + 1 - N_RING;                            // drain piece p while the later ones fly
+        if (p >= np) break;
+        const int pb = (int) (p % N_RING);
+        if (wait_event(c.ev_pin_dn[pb])) return -1;
+        const uint8_t *chunk = (const uint8_t *) c.pin_dn[pb];
+        const uint64_t c0 = p * RING_CHUNK, c1 = c0 + (total - c0 < RING_CHUNK ? total - c0 : RING_CHUNK);
+        if (!dst) { par_memcpy(flat + c0, chunk, c1 - c0, threads); continue; }
+        while (row_lo < rows && off[row_lo] + len[row_lo] <= c0) ++row_lo;
+        uint64_t row_hi = row_lo;
+        while (row_hi < rows && off[row_hi] < c1) ++row_hi;
+        if (threads <= 1) {
+            for (uint64_t r = row_lo; r < row_hi; ++r) {
+                const uint64_t a = off[r] > c0 ? off[r] : c0, e = off[r] + len[r] < c1 ? off[r] + len[r] : c1;
+                if (e > a) memcpy(dst[r] + (a - off[r]), chunk + (a - c0), e - a);
+            }
+        } else {
+#pragma omp parallel for schedule(static) num_threads(threads)
             for (uint64_t r = row_lo; r < row_hi; ++r) {
                 const uint64_t a = off[r] > c0 ? off[r] : c0, e = off[r] + len[r] < c1 ? off[r] + len[r] : c1;
                 if (e > a) memcpy(dst[r] + (a - off[r]), chunk + (a - c0), e - a);
             }
         }
-        if (l == 0) break;
-        prev_o = o; prev_l = l; o += l; ++k;
     }
     return 0;
 }
@@ -351,10 +343,14 @@ uint64_t pipe_subs(uint64_t n, const LrmMapTune &mt) {
 // Sub-batches per extension group: the bit-sliced kernel carries one read per LANE, so it wants >= 32 k reads
 // per launch for decent SIMD coverage; two groups are in extension at once (two streams).  Measured per 100 k-read
 // batch [r2, one batch at a time]: groups of 17 k reads 69 ms, 25 k 73 ms, 33 k 78 ms.
-constexpr uint64_t EXT_GROUP_READS = 16384;
-uint64_t ext_group_subs(uint64_t sub, uint64_t nsub, const LrmMapTune &mt) {
+// With ANOTHER slice in flight on the device the chain inside one slice no longer matters, the fill of the chip does:
+// groups of ~50 k reads (two per 100 k-read batch: 41.4 ms per batch with two in flight against 48.3 with groups of
+// 17 k [r3]; a single call prefers the small groups: 58.0 against 62.0).
+constexpr uint64_t EXT_GROUP_READS = 16384, EXT_GROUP_READS_BUSY = 49152;
+uint64_t ext_group_subs(uint64_t sub, uint64_t nsub, const LrmMapTune &mt, bool busy) {
     if (mt.group_subs >= 1) return mt.group_subs < nsub ? mt.group_subs : nsub;
-    const uint64_t g = (EXT_GROUP_READS + sub - 1) / (sub ? sub : 1);
+    const uint64_t want = busy ? EXT_GROUP_READS_BUSY : EXT_GROUP_READS;
+    const uint64_t g = (want + sub - 1) / (sub ? sub : 1);
     return g < 1 ? 1 : (g > nsub ? nsub : g);
 }
 
@@ -386,6 +382,7 @@ struct SliceJob {
     lrm_ticket *ticket = nullptr;
     uint32_t max_len = 0;
     Slot *slot = nullptr;
+    bool busy = false;                // another slice was queued or in flight when this one was issued
     // plan (made by the issuer)
     std::vector<Range> subs, units;
     std::vector<size_t> ends, unit_of;
@@ -437,7 +434,7 @@ int plan_and_issue(LrmHostCtx &c, SliceJob &sj) {
     std::vector<Range> &subs = sj.subs, &units = sj.units;
     std::vector<size_t> &ends = sj.ends, &unit_of = sj.unit_of;
     for (uint64_t off = 0; off < n; off += sub) subs.push_back({off, n - off < sub ? n - off : sub});
-    const uint64_t gsub = (j.mode & DO_EXTEND) ? ext_group_subs(sub, subs.size(), mt) : 1;
+    const uint64_t gsub = (j.mode & DO_EXTEND) ? ext_group_subs(sub, subs.size(), mt, sj.busy) : 1;
     for (size_t k = gsub; k < subs.size(); k += gsub) ends.push_back(k);
     ends.push_back(subs.size());
     unit_of.resize(subs.size());
@@ -540,30 +537,28 @@ int collect(LrmHostCtx &c, SliceJob &sj, size_t g) {
     memcpy(j.meta + o, h_meta, m * sizeof(lrm_seq_meta));
     memcpy(j.meta_r + o, h_mr, m * 4);
 
-    // dense image of the unit: the used part of every CIGAR row, then the reads that were reverse-complemented in
-    // place (alnmain.c:437; the other rows of reads_buf did not change)
-    void *store_alias = nullptr, *reads_alias = nullptr;
+    // Dense image of the unit on the device: the used part of every CIGAR row, then the reads that were
+    // reverse-complemented in place (alnmain.c:437; the other rows of reads_buf did not change).  Everything crosses
+    // the link by DMA (hipMemcpyAsync): a hand-written kernel that writes the caller's pinned memory runs at the link
+    // rate on an idle chip and at 2-9 GB/s once the compute kernels of the batches in flight own the wave slots, stream
+    // priority or not, while the DMA keeps 50-57 GB/s (tools/d2h_under_load.hip, profiles/r3/probes).
     uint8_t *h_store = j.store_mem + o * j.store_stride;
-    const bool pin_store = is_pinned(h_store, &store_alias), pin_reads = is_pinned(j.reads + o * j.stride, &reads_alias);
-    const bool want_direct = sj.mt.direct_rows != 0;                 // -1 automatic: on whenever the caller's buffer is pinned
+    const bool pin_store = is_pinned(h_store);
     const bool dense = sj.mt.dense != 0;
-    const bool direct_ops = !dense && want_direct && pin_store && store_alias;
-    const bool direct_reads = want_direct && pin_reads && reads_alias;
     uint64_t total_ops = 0, total = 0;
     for (uint64_t i = 0; i < m; ++i) {
         const uint64_t cap = j.store_stride;
         h_len[i] = h_nops[i] > 0 ? (uint32_t) ((uint64_t) h_nops[i] < cap ? (uint64_t) h_nops[i] : cap) : 0u;
-        h_off[i] = total;
-        total += ((uint64_t) h_len[i] + 15) & ~15ull;
+        h_off[i] = total_ops;
+        total_ops += ((uint64_t) h_len[i] + 15) & ~15ull;
     }
-    total_ops = total;
-    if (direct_ops) total = 0;
+    total = total_ops;
     uint64_t n_rev = 0;
     for (uint64_t i = 0; i < m; ++i) {
         const bool rev = h_mr[i] != 0 && h_meta[i].strand == 1;
         h_len[m + i] = rev ? j.lens[o + i] : 0u;
         h_off[m + i] = total;
-        if (!direct_reads) total += ((uint64_t) h_len[m + i] + 15) & ~15ull;
+        total += ((uint64_t) h_len[m + i] + 15) & ~15ull;
         n_rev += rev;
     }
     const int b = (int) (g & 1);
@@ -572,55 +567,39 @@ int collect(LrmHostCtx &c, SliceJob &sj, size_t g) {
     uint64_t *d_off = (uint64_t *) S.offs[b].p;
     uint32_t *d_len = (uint32_t *) ((uint8_t *) S.offs[b].p + 2 * m * 8);
     uint8_t *dn = (uint8_t *) S.dense[b].p;
-    if (total_ops || n_rev) {
+    if (total) {
         HIPCHK(hipMemcpyAsync(d_len, h_len, 2 * m * 4, hipMemcpyHostToDevice, c.down));
         HIPCHK(hipMemcpyAsync(d_off, h_off, 2 * m * 8, hipMemcpyHostToDevice, c.down));
         const uint32_t gy_ops = (uint32_t) ((j.store_stride + 4095) / 4096), gy_rd = (uint32_t) ((j.stride + 4095) / 4096);
-        if (total_ops) {
-            if (direct_ops)
-                hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t) m, gy_ops ? gy_ops : 1), dim3(256), 0, c.down, d_store, dstride,
-                                   (uint8_t *) store_alias, j.store_stride, d_len, m);
-            else
-                hipLaunchKernelGGL(pack_rows_kernel, dim3((uint32_t) m, gy_ops ? gy_ops : 1), dim3(256), 0, c.down, d_store, dstride,
-                                   d_len, d_off, dn, m);
-        }
-        if (n_rev) {
-            if (direct_reads)
-                hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t) m, gy_rd ? gy_rd : 1), dim3(256), 0, c.down, d_reads, j.stride,
-                                   (uint8_t *) reads_alias, j.stride, d_len + m, m);
-            else
-                hipLaunchKernelGGL(pack_rows_kernel, dim3((uint32_t) m, gy_rd ? gy_rd : 1), dim3(256), 0, c.down, d_reads, j.stride,
-                                   d_len + m, d_off + m, dn, m);
-        }
+        if (n_rev)
+            hipLaunchKernelGGL(pack_rows_kernel, dim3((uint32_t) m, gy_rd ? gy_rd : 1), dim3(256), 0, c.down, d_reads, j.stride,
+                               d_len + m, d_off + m, dn, m);
+        if (total_ops)
+            hipLaunchKernelGGL(pack_rows_kernel, dim3((uint32_t) m, gy_ops ? gy_ops : 1), dim3(256), 0, c.down, d_store, dstride,
+                               d_len, d_off, dn, m);
         HIPCHK(hipGetLastError());
-        if (dense && total_ops) {
-            // DENSE results: the op bytes of the unit land back to back at the start of the region of store_mem its rows
-            // would occupy (sum of the 16-aligned lengths <= m * store_stride because store_stride % 16 == 0)
-            if (pin_store) {
-                HIPCHK(hipMemcpyAsync(h_store, dn, total_ops, hipMemcpyDeviceToHost, c.down));
-            } else {
-                for (uint64_t x = 0, k = 0; x < total_ops; x += STAGE_CHUNK, ++k) {
-                    const int pb = (int) (k & 1);
-                    const uint64_t l = total_ops - x < STAGE_CHUNK ? total_ops - x : STAGE_CHUNK;
-                    HIPCHK(hipMemcpyAsync(c.pin_dn[pb], dn + x, l, hipMemcpyDeviceToHost, c.down));
-                    HIPCHK(hipEventRecord(c.ev_pin_dn[pb], c.down));
-                    if (wait_event(c.ev_pin_dn[pb])) return -1;
-                    par_memcpy(h_store + x, c.pin_dn[pb], l, c.copy_threads);
-                }
-            }
+        std::vector<uint8_t *> dst(2 * m);
+        for (uint64_t i = 0; i < m; ++i) {
+            dst[i] = j.store_mem + (o + i) * j.store_stride;
+            dst[m + i] = (uint8_t *) j.reads + (o + i) * j.stride;
         }
-        // what still has to be scattered into strided caller rows by the host
-        const uint64_t sc_lo = dense || direct_ops ? m : 0, sc_hi = direct_reads ? m : 2 * m;
-        if (sc_hi > sc_lo && total > (dense ? total_ops : 0)) {
-            std::vector<uint8_t *> dst(2 * m);
-            for (uint64_t i = 0; i < m; ++i) {
-                dst[i] = j.store_mem + (o + i) * j.store_stride;
-                dst[m + i] = (uint8_t *) j.reads + (o + i) * j.stride;
-            }
-            const uint64_t base = h_off[sc_lo];
-            std::vector<uint64_t> roff(sc_hi - sc_lo);
-            for (uint64_t i = sc_lo; i < sc_hi; ++i) roff[i - sc_lo] = h_off[i] - base;
-            if (d2h_scatter(c, dn + base, total - base, roff.data(), h_len + sc_lo, dst.data() + sc_lo, sc_hi - sc_lo)) return -1;
+        if (dense) {
+            // The reverse-complemented reads are the only rows the host has to place: through the chunk ring, copied by
+            // this thread alone.  Then the op bytes: ONE DMA straight into the region of the caller's pinned store_mem
+            // the unit's rows would occupy (sum of the 16-aligned lengths <= m * store_stride because
+            // store_stride % 16 == 0) -- it flies while this thread goes on to the next unit.
+            auto ops_dma = [&]() -> int {
+                if (total_ops && pin_store) HIPCHK(hipMemcpyAsync(h_store, dn, total_ops, hipMemcpyDeviceToHost, c.down));
+                return 0;
+            };
+            std::vector<uint64_t> roff(m);
+            for (uint64_t i = 0; i < m; ++i) roff[i] = h_off[m + i] - total_ops;
+            if (d2h_ring(c, dn + total_ops, total - total_ops, roff.data(), h_len + m, dst.data() + m, m, nullptr, 1, ops_dma)) return -1;
+            if (total_ops && !pin_store && d2h_ring(c, dn, total_ops, nullptr, nullptr, nullptr, 0, h_store, c.copy_threads, []() { return 0; })) return -1;
+        } else {
+            // row layout (alnmain.c:322-325): every used CIGAR row and every reverse-complemented read is placed by the
+            // host's memcpy team
+            if (d2h_ring(c, dn, total, h_off, h_len, dst.data(), 2 * m, nullptr, c.copy_threads, []() { return 0; })) return -1;
         }
         HIPCHK(hipEventRecord(S.ev_dense[b], c.down));
         S.dense_used[b] = true;
@@ -630,9 +609,8 @@ int collect(LrmHostCtx &c, SliceJob &sj, size_t g) {
         j.cig[o + i].n_cigar_op = h_nops[i];
         j.cig[o + i].score = h_score[i];
     }
-    if (sj.clk.on) fprintf(stderr, "[lrm host] collect off=%llu m=%llu: wait-from %.1f kernels-done %.1f issued %.1f ms (%s ops, %s reads, %.0f MB)\n",
-                           (unsigned long long) o, (unsigned long long) m, t_in, t_done, sj.clk.ms(), dense ? "dense" : direct_ops ? "direct" : "scatter",
-                           direct_reads ? "direct" : "scatter", (total_ops + (double) n_rev * sj.max_len) / 1e6);
+    if (sj.clk.on) fprintf(stderr, "[lrm host] collect off=%llu m=%llu: wait-from %.1f kernels-done %.1f issued %.1f ms (%s, %.0f MB)\n",
+                           (unsigned long long) o, (unsigned long long) m, t_in, t_done, sj.clk.ms(), dense ? (pin_store ? "dense, DMA into store_mem" : "dense, staged") : "rows", total / 1e6);
     return 0;
 }
 
@@ -647,16 +625,17 @@ void issuer_main(LrmHostCtx *cp) {
             c.cv.wait(lk, [&] {
                 if (c.stop) return true;
                 if (c.q_issue.empty()) return false;
-                for (auto &s : c.slots) if (!s.busy) return true;
+                for (int k = 0; k < c.n_slots; ++k) if (!c.slots[k].busy) return true;
                 return false;
             });
             if (c.stop && c.q_issue.empty()) return;
             if (c.q_issue.empty()) continue;
-            for (auto &s : c.slots) if (!s.busy) { slot = &s; break; }
+            for (int k = 0; k < c.n_slots; ++k) if (!c.slots[k].busy) { slot = &c.slots[k]; break; }
             if (!slot) continue;
             slot->busy = true;
             job = std::move(c.q_issue.front());
             c.q_issue.pop_front();
+            job->busy = c.n_active > 1;
         }
         SliceJob *sj = job.get();
         sj->slot = slot;
@@ -747,6 +726,7 @@ int ensure_ctx(lrm_index *idx, int group_size) {
     // replicas of a group share the host's CPU share
     int ct = lrm_host_threads() / (group_size > 0 ? group_size : 1);
     c.copy_threads = ct < 1 ? 1 : (ct > 8 ? 8 : ct);
+    { long long v; if (idx->env.get("LRM_HOST_SLOTS", &v) && v >= 1 && v <= N_SLOTS) c.n_slots = (int) v; }
     if (!c.threads_up) {
         try {
             c.issuer = std::thread(issuer_main, &c);
@@ -893,8 +873,10 @@ void lrm_host_ctx_free(lrm_index *idx) {
     }
     for (int b = 0; b < 2; ++b) {
         if (c->pin_up[b]) (void) hipHostFree(c->pin_up[b]);
-        if (c->pin_dn[b]) (void) hipHostFree(c->pin_dn[b]);
         if (c->ev_pin_up[b]) (void) hipEventDestroy(c->ev_pin_up[b]);
+    }
+    for (int b = 0; b < N_RING; ++b) {
+        if (c->pin_dn[b]) (void) hipHostFree(c->pin_dn[b]);
         if (c->ev_pin_dn[b]) (void) hipEventDestroy(c->ev_pin_dn[b]);
     }
     if (c->ev_small) (void) hipEventDestroy(c->ev_small);

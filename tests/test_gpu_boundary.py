@@ -46,11 +46,10 @@ def _dense_rows(got):
 
 
 @pytest.mark.parametrize("opts", [None, {}, {"sub_batches": 4}, {"slice_reads": 9, "sub_batches": 2},
-                                  {"dense_results": 1}, {"dense_results": 1, "slice_reads": 13, "sub_batches": 3, "group_subs": 1},
-                                  {"direct_rows": 0}, {"direct_rows": 1}])
+                                  {"dense_results": 1}, {"dense_results": 1, "slice_reads": 13, "sub_batches": 3, "group_subs": 1}])
 def test_map_batch_equals_the_two_calls_and_the_oracle(ont, opts):
     """lrm_map_batch = lrm_seed_batch + lrm_extend_batch in one device pass (one upload of the reads), in every result
-    mode of lrm_map_options: rows / dense, any slicing, device row writes or host scatter."""
+    mode of lrm_map_options: rows / dense, any slicing."""
     sc, di, oi, best, ext, r_cpu = ont
     r = sc["reads"].copy()
     got = mapper.map_batch(di, r, sc["lens"], sc["seed_len"], sc["thres"], options=opts)
@@ -64,7 +63,7 @@ def test_map_batch_equals_the_two_calls_and_the_oracle(ont, opts):
     assert np.array_equal(r, r_cpu)                      # reverse-strand reads rev-comped in the caller's buffer
 
 
-@pytest.mark.parametrize("opts", [{}, {"dense_results": 1}, {"dense_results": 1, "direct_rows": 0}])
+@pytest.mark.parametrize("opts", [{}, {"dense_results": 1}])
 @pytest.mark.parametrize("pinned", [False, True])
 def test_two_batches_in_flight(ont, opts, pinned):
     """lrm_map_batch_submit / lrm_map_batch_wait: three batches submitted back to back (two in flight on the device,
@@ -111,8 +110,8 @@ def test_dense_results_need_an_aligned_stride(ont):
 
 
 def test_map_batch_with_pinned_caller_buffers(ont):
-    """Buffers from lrm_host_alloc are handed to the DMA engines directly (no staging copy) and the device writes the
-    result rows straight into them: same results; also with direct_rows = 0 (dense DMA + host scatter)."""
+    """Buffers from lrm_host_alloc are handed to the DMA engines directly (no staging copy): same results in the row
+    layout and in the dense one (op bytes DMA'd straight into the pinned store_mem)."""
     sc, di, oi, best, ext, r_cpu = ont
     n, stride = sc["reads"].shape
     r = mapper.pinned_empty((n, stride))
@@ -124,12 +123,15 @@ def test_map_batch_with_pinned_caller_buffers(ont):
         assert np.array_equal(got["best"], best)
         _assert_ext_equal(got, ext, n, "pinned")
         assert np.array_equal(r, r_cpu)
-        for direct in (0, 1):
-            r[:] = sc["reads"]
-            store[:] = 0
-            got = mapper.map_batch(di, r, sc["lens"], sc["seed_len"], sc["thres"], store=store, options={"direct_rows": direct})
+        r[:] = sc["reads"]
+        dstore = mapper.pinned_empty((n, (2 * (stride - 1) + 15) // 16 * 16))
+        try:
+            dstore[:] = 0
+            got = mapper.map_batch(di, r, sc["lens"], sc["seed_len"], sc["thres"], store=dstore, options={"dense_results": 1})
             assert np.array_equal(got["best"], best) and np.array_equal(r, r_cpu)
-            _assert_ext_equal(got, ext, n, "pinned, direct_rows=%d" % direct)
+            _assert_ext_equal(_dense_rows(got), ext, n, "pinned, dense")
+        finally:
+            mapper.pinned_free(dstore)
         # registered caller memory (what a maintainer does with the malloc'd buffers of alnmain.c:297-320)
         r2 = np.ascontiguousarray(sc["reads"].copy())
         capi.check(capi.lib.lrm_host_register(r2.ctypes.data, r2.nbytes), "lrm_host_register")

@@ -11,7 +11,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from longreadmapper_amd import index, mapper, synth
+from longreadmapper_amd import capi, index, mapper, synth
 
 
 def cpu_s():
@@ -32,7 +32,10 @@ for var in (sys.argv[1:] or [""]):
     kv = dict(x.split("=") for x in var.split()) if var else {}
     inflight = int(kv.pop("inflight", 1))
     kind = kv.pop("buf", "pinned")
-    steps = int(kv.pop("steps", 6))
+    steps = int(kv.pop("steps", 10))
+    envs = {k: kv.pop(k) for k in list(kv) if k.startswith("LRM_")}          # tuning overrides, re-read for this variant
+    os.environ.update(envs)
+    capi.lib.lrm_debug_reload_env(di.handle)
     opts = {k: int(v) for k, v in kv.items()}
     if kind not in bufs:
         bufs[kind] = [(np.empty((n, Lr + 1), dtype=np.uint8), np.empty((n, sstride), dtype=np.uint8)) for _ in range(NBUF)]
@@ -40,9 +43,8 @@ for var in (sys.argv[1:] or [""]):
     for hr, hs in bb:
         hr[:] = r["reads"]
     res = mapper.map_batch(di, bb[0][0], r["lens"], store=bb[0][1], options=opts)      # warm-up (mirrors, workspaces)
-    if inflight > 1:
-        p = [mapper.map_batch_submit(di, bb[k][0], r["lens"], store=bb[k][1], options=opts) for k in (1, 2)]
-        [x.wait() for x in p]
+    p = [mapper.map_batch_submit(di, bb[k][0], r["lens"], store=bb[k][1], options=opts) for k in (1, 2, 0)]    # warm-up in flight
+    [x.wait() for x in p]
     if base is None:
         base = (res["best"].copy(), res["score"].copy(), res["n_ops"].copy())
     same = np.array_equal(res["best"], base[0]) and np.array_equal(res["score"], base[1]) and np.array_equal(res["n_ops"], base[2])
@@ -61,5 +63,7 @@ for var in (sys.argv[1:] or [""]):
         pend.pop(0).wait()
     wall, cpu = time.perf_counter() - t0, cpu_s() - c0
     gbp = steps * n * Lr / 1e9
+    for k in envs:
+        del os.environ[k]
     print("%-52s %-8s inflight %d: %6.1f ms per batch  %5.2f Gbp/s  host CPU %.3f s per Gbp  same=%s"
-          % (" ".join("%s=%s" % kv_ for kv_ in opts.items()) or "(defaults)", kind, inflight, 1e3 * wall / steps, gbp / wall, cpu / gbp, same), flush=True)
+          % (" ".join("%s=%s" % kv_ for kv_ in list(opts.items()) + list(envs.items())) or "(defaults)", kind, inflight, 1e3 * wall / steps, gbp / wall, cpu / gbp, same), flush=True)
