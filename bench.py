@@ -9,19 +9,31 @@ ONT-profile reads, seed_len 20, thres 300 (reference defaults), GACT T=320 O=120
   python bench.py --gpus N --steps K --warmup W        (N>1: launched under torch.distributed.run)
 
 Rank 0 prints ONE JSON line:
-  value            HBM-resident rate of the timed steps (the contract's `value`)
-  pcie_inclusive   SURVEY 8(d)'s metric: the same batch through the drop-in boundary lrm_map_batch on CALLER
-                   buffers -- H2D of the reads and D2H of every result inside the timed region -- with pinned
-                   (lrm_host_alloc) and with pageable (malloc, what alnmain.c has today) buffers
+  value / value_hbm_resident   HBM-resident rate of the timed steps (the contract's `value`)
+  value_pcie_inclusive         SURVEY 8(d)'s metric: the same batches through the drop-in boundary on CALLER buffers --
+                               H2D of the reads and D2H of every result inside the timed region; details in
+                               `pcie_inclusive`: batches in flight (lrm_map_batch_submit / _wait), one call at a time
+                               (lrm_map_batch), dense / row result layout, pinned / pageable buffers, and the host CPU
+                               seconds the process spent per Gbp
   roofline         dominant kernel of a SERIALIZED replay of the same steps on one stream (every kernel has the
-                   chip to itself: kernel time <= step time), algorithmic bytes / HIP-event time vs 8 TB/s
+                   chip to itself: kernel time <= step time).  `frac` = bytes the DEVICE layout must move / time / 8 TB/s
+                   (counted by the counting build of the seed kernel), `traffic_frac` = the bytes really moved (64-byte
+                   lines, committed PMC passes), `random_line_rate` = L2 misses per second against the measured ceiling
+                   of independent random 64-byte lines (tools/randline_bench.hip), `reference_work_rate` = the
+                   reference layout's algorithmic bytes per second -- a rate of reference work, not a
+                   fraction of anything
   cpu_baseline     the CPU oracle on a bounded sample of the same reads: all host cores and 1 thread
                    (the reference's own configuration: both pragmas are commented out, alnmain.c:327-328)
+  grch38           the same measurement on the north-star configuration (GRCh38-sized text, 3.1 Gbp, 100 k x 10 kbp ONT
+                   reads per step, one GPU) from a fresh child process, when the host has the memory for the index build
   kernels / isolated.kernels   per-kernel tables of the timed (overlapped) region and of the replay
 """
 import argparse
+import gc
 import json
 import os
+import resource
+import subprocess
 import sys
 import time
 
@@ -34,6 +46,8 @@ ECOLI_N = 4_641_652
 CHR1_N = 248_956_422
 GRCH38_N = 3_099_750_718    # GRCh38 primary assembly incl. unplaced scaffolds (no FASTA on the box: synthetic of this size)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+RANDOM_LINES_PER_S = 50.4e9  # independent random 64-byte lines per second over a 64 GiB buffer, whatever the loads in
+                             # flight per lane or the occupancy (tools/randline_bench.hip, profiles/r3/probes/randline_bench.jsonl)
 
 
 def log(*a):
@@ -54,8 +68,40 @@ def usable_cpus():
 
 
 def peak_rss_gb():
-    import resource
     return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
+
+
+def process_cpu_s():
+    u = resource.getrusage(resource.RUSAGE_SELF)      # every thread of this process, user + system
+    return u.ru_utime + u.ru_stime
+
+
+def host_gb_available():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                gb = int(line.split()[1]) / 1e6
+                break
+        else:
+            return 0.0
+        for p in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+            try:
+                v = open(p).read().strip()
+                if v != "max":
+                    used = 0
+                    for q in ("/sys/fs/cgroup/memory.current", "/sys/fs/cgroup/memory/memory.usage_in_bytes"):
+                        try:
+                            used = int(open(q).read())
+                            break
+                        except OSError:
+                            pass
+                    gb = min(gb, (int(v) - used) / 1e9)
+                break
+            except OSError:
+                pass
+        return gb
+    except OSError:
+        return 0.0
 
 
 def load_pmc_summary(args, n, Lr):
@@ -64,17 +110,17 @@ def load_pmc_summary(args, n, Lr):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")))
     if not files:
-        return None
+        return None, None
     try:
         d = json.load(open(files[-1]))
         w = d["workload"]
         if (w["reads_per_gpu"], w["read_len"], w["seed_len"], w["thres"]) != (n, Lr, args.seed_len, args.thres):
-            return None
+            return None, None
         if args.ref_len != ECOLI_N or args.profile != "ont":
-            return None
-        return d["kernels"]
+            return None, None
+        return d["kernels"], os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
+        return None, None
 
 
 def main():
@@ -91,13 +137,17 @@ def main():
     ap.add_argument("--gact", default="320,120,128")
     ap.add_argument("--no-isolated-replay", action="store_true",
                     help="skip the serialized replay of the steps on one stream that `roofline` is taken from")
-    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg through lrm_map_batch")
-    ap.add_argument("--pcie-steps", type=int, default=0, help="steps of the PCIe-inclusive leg (default: min(steps, 8))")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive legs through the host-buffer boundary")
+    ap.add_argument("--pcie-steps", type=int, default=0, help="batches of every PCIe-inclusive leg (default: min(steps, 10))")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("LRM_BENCH_STREAMS", "3")),
                     help="HIP streams the steps alternate over (each with its own workspace); >1 overlaps the "
                          "HBM-latency-bound seed kernels of one step with the VALU-bound extension of another")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0: skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-grch38", action="store_true",
+                    help="do not run the GRCh38-sized leg in a child process after the default workload")
+    ap.add_argument("--grch38-timeout", type=float, default=400.0)
+    ap.add_argument("--sa-sampled", type=int, default=0, help="lrm_index_options.sa_sampled (0: full suffix array)")
     args = ap.parse_args()
 
     # OpenMP (index builder, staging copies, the CPU oracle) must not spawn one thread per hardware thread of the
@@ -105,6 +155,7 @@ def main():
     # (and the ranks of one node share that share)
     os.environ.setdefault("OMP_NUM_THREADS", str(max(1, usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))))))
 
+    t_start = time.time()
     import torch
     import torch.distributed as tdist
     from longreadmapper_amd import dist, index, mapper, synth
@@ -118,6 +169,7 @@ def main():
     dev = torch.device("cuda", local)
     gact = tuple(int(x) for x in args.gact.split(","))
     prof = {"ont": synth.ONT, "pacbio": synth.PACBIO_CLR, "clean": synth.CLEAN}[args.profile]
+    iopts = dict(sa_sampled=args.sa_sampled) if args.sa_sampled else {}
 
     # ---- index: built on the CPU by rank 0, one RCCL broadcast of the device image -----------------
     t0 = time.time()
@@ -131,7 +183,7 @@ def main():
         hi = index.HostIndex.build([ref], names=["synth_ref"], o_ratio=32, hlen=12)
         t_build = time.time() - t1
         t1 = time.time()
-        blob = hi.pack_device(local)          # packed piece by piece straight into HBM: no host copy of the image
+        blob = hi.pack_device(local, **iopts)          # packed piece by piece straight into HBM: no host copy of the image
         torch.cuda.synchronize()
         t_pack = time.time() - t1
         log("index: N=%d L=%d: reference %.1fs, built in %.1fs, image %.2f GiB packed+uploaded in %.1fs"
@@ -173,6 +225,12 @@ def main():
             tdist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev if tdist.is_initialized() and tdist.get_backend() == "nccl" else "cpu")
+        if world > 1:
+            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -193,7 +251,7 @@ def main():
                     ktimes[name] = (a[0] + ms, a[1] + launches)
             sl["dm"].set_timing(False)
     # serialized replay of the same steps on ONE stream: per-kernel durations without the other streams' kernels
-    # sharing the chip (the timed region above is what `value` and `roofline` come from)
+    # sharing the chip (the timed region above is what `value` comes from, the replay what `roofline` comes from)
     ktimes_iso = {}
     iso_wall = None
     if not args.no_isolated_replay and not args.no_kernel_timing and rank == 0:
@@ -210,50 +268,113 @@ def main():
         with torch.cuda.stream(slots[0]["stream"]):
             ktimes_iso = slots[0]["dm"].timing()
         slots[0]["dm"].set_timing(False)
+    # the memory requests the DEVICE layout makes (counting build of the seed kernel, outside every timed region)
+    dev_counts = None
+    if rank == 0:
+        with torch.cuda.stream(slots[0]["stream"]):
+            slots[0]["reads"].copy_(pristine)
+            slots[0]["dm"].set_counting(True)
+            slots[0]["dm"].seed(slots[0]["reads"], d_lens)
+            dev_counts = slots[0]["dm"].stats()
+            slots[0]["dm"].set_counting(False)
+            slots[0]["dm"].seed(slots[0]["reads"], d_lens)         # leaves best[] of the product kernel for the checks below
+            slots[0]["dm"].extend(slots[0]["reads"], d_lens)
+        torch.cuda.synchronize()
+    elapsed = max_over_ranks(elapsed)
+    stats = dm.stats()
+    full = dm.results(n) if rank == 0 else None
+
     # ---- the same batch through the drop-in boundary on caller buffers (H2D + D2H timed) ----------
     pcie = None
     if not args.no_pcie:
-        ps = args.pcie_steps or min(args.steps, 8)
+        # the device-resident slots are no longer needed: their HBM goes back before the host path allocates its own
+        for sl in slots[1:]:
+            sl["dm"].close()
+        del slots[1:]
+        torch.cuda.empty_cache()
+        ps = args.pcie_steps or min(args.steps, 10)
         stride = r["reads"].shape[1]
-        pcie = dict(steps=ps, entry_point="lrm_map_batch (seed + extend in one device pass; reads cross the link once)")
-        for kind in ("pinned", "pageable"):
-            if kind == "pinned":
-                hr = mapper.pinned_empty((n, stride))
-                hs = mapper.pinned_empty((n, 2 * Lr))
-            else:
-                hr = np.empty((n, stride), dtype=np.uint8)
-                hs = np.empty((n, 2 * Lr), dtype=np.uint8)
-            hs[:] = 0
-            hr[:] = r["reads"]
-            mapper.map_batch(di, hr, r["lens"], args.seed_len, args.thres, gact, store=hs)      # warm-up: device mirrors, workspace
-            barrier()
-            tp = 0.0
-            for _ in range(ps):
-                hr[:] = r["reads"]                                                             # untimed: the caller's batch load
-                barrier()
-                t1 = time.perf_counter()
-                res_p = mapper.map_batch(di, hr, r["lens"], args.seed_len, args.thres, gact, store=hs)
-                barrier()
-                tp += time.perf_counter() - t1
-            tq = torch.tensor([tp], dtype=torch.float64, device=dev if tdist.is_initialized() and tdist.get_backend() == "nccl" else "cpu")
-            if world > 1:
-                tdist.all_reduce(tq, op=tdist.ReduceOp.MAX)
-            pcie[kind] = dict(value=bases * world * ps / float(tq.item()) / 1e9, unit="Gbp/s", ms_per_step=float(tq.item()) / ps * 1e3)
-            if kind == "pinned":
-                pcie_res = dict(best=res_p["best"].copy(), score=res_p["score"].copy(), n_ops=res_p["n_ops"].copy())
-                mapper.pinned_free(hr)
-                mapper.pinned_free(hs)
-            del hr, hs
-        pcie["value"] = pcie["pinned"]["value"]
-        pcie["unit"] = "Gbp/s"
-        pcie["bytes_per_step"] = dict(h2d=int(n * stride + 4 * n), d2h_reads=int(n * stride),
-                                      d2h_ops="used columns of the op-byte buffer (n x max n_ops rounded to 64)")
+        sstride = (2 * Lr + 15) // 16 * 16
+        NB = 3                                       # caller buffer sets: two batches on the device, one queued
+        pcie = dict(steps=ps, note="every leg: H2D of the reads and D2H of every result (best[], scores, loci, op bytes, "
+                                   "reverse-complemented reads) inside the timed region; the caller's own batch load (copying "
+                                   "the reads into the buffer) is untimed")
 
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if tdist.is_initialized() and tdist.get_backend() == "nccl" else "cpu")
-    if world > 1:
-        tdist.all_reduce(tt, op=tdist.ReduceOp.MAX)
-    elapsed = float(tt.item())
-    stats = dm.stats()
+        def leg(kind, dense, inflight):
+            if kind == "pinned":
+                bufs = [(mapper.pinned_empty((n, stride)), mapper.pinned_empty((n, sstride))) for _ in range(NB if inflight > 1 else 1)]
+            else:
+                bufs = [(np.empty((n, stride), dtype=np.uint8), np.empty((n, sstride), dtype=np.uint8)) for _ in range(NB if inflight > 1 else 1)]
+            opts = dict(dense_results=1) if dense else {}
+            for hr, hs in bufs:
+                hs[:] = 0
+                hr[:] = r["reads"]
+            # warm-up: device mirrors, workspaces, both slots
+            w = [mapper.map_batch_submit(di, hr, r["lens"], args.seed_len, args.thres, gact, store=hs, options=opts) for hr, hs in bufs]
+            res = [x.wait() for x in w][0]
+            res = dict(best=res["best"].copy(), score=res["score"].copy(), n_ops=res["n_ops"].copy(),
+                       ops0=[mapper.ops_of(res, i) for i in range(min(n, 64))], reads0=bufs[0][0][:64].copy())
+            for hr, hs in bufs:
+                hr[:] = r["reads"]                                                             # untimed: the caller's batch load
+            barrier()
+            if inflight == 1:
+                # one call at a time (submit + wait == lrm_map_batch): the batch is restored before every call, untimed
+                wall = cpu = 0.0
+                for s in range(ps):
+                    hr, hs = bufs[0]
+                    hr[:] = r["reads"]
+                    barrier()
+                    c0, t1 = process_cpu_s(), time.perf_counter()
+                    mapper.map_batch_submit(di, hr, r["lens"], args.seed_len, args.thres, gact, store=hs, options=opts).wait()
+                    barrier()
+                    wall += time.perf_counter() - t1
+                    cpu += process_cpu_s() - c0
+            else:
+                # batches in flight: the buffers are re-used as they come back.  Reads of a buffer that has been through a
+                # batch are partly reverse-complemented; mapping them again is the same work -- restoring 1 GB per batch
+                # inside the loop would time the host's memcpy, not the path.
+                c0, t1 = process_cpu_s(), time.perf_counter()
+                pend = []
+                for s in range(ps):
+                    hr, hs = bufs[s % len(bufs)]
+                    pend.append(mapper.map_batch_submit(di, hr, r["lens"], args.seed_len, args.thres, gact, store=hs, options=opts))
+                    if len(pend) >= inflight:
+                        pend.pop(0).wait()
+                while pend:
+                    pend.pop(0).wait()
+                barrier()
+                wall, cpu = time.perf_counter() - t1, process_cpu_s() - c0
+            wall = max_over_ranks(wall)
+            out = dict(value=bases * world * ps / wall / 1e9, unit="Gbp/s", ms_per_batch=wall / ps * 1e3,
+                       host_cpu_s_per_Gbp=cpu / (bases * ps / 1e9), buffers=kind, result_layout="dense" if dense else "rows",
+                       batches_submitted_ahead=inflight)
+            if kind == "pinned":
+                for hr, hs in bufs:
+                    mapper.pinned_free(hr)
+                    mapper.pinned_free(hs)
+            del bufs
+            return out, res
+
+        legs = [("in_flight_dense_pinned", "pinned", True, 3), ("one_call_dense_pinned", "pinned", True, 1),
+                ("one_call_rows_pinned", "pinned", False, 1), ("one_call_rows_pageable", "pageable", False, 1),
+                ("in_flight_rows_pageable", "pageable", False, 3)]
+        pcie_res = {}
+        for name, kind, dense, infl in legs:
+            pcie[name], pcie_res[name] = leg(kind, dense, infl)
+            if rank == 0:
+                log("pcie leg %-26s %6.2f Gbp/s  %6.1f ms per batch  host CPU %.3f s per Gbp"
+                    % (name, pcie[name]["value"], pcie[name]["ms_per_batch"], pcie[name]["host_cpu_s_per_Gbp"]))
+        pcie["value"] = pcie["in_flight_dense_pinned"]["value"]
+        pcie["unit"] = "Gbp/s"
+        pcie["value_leg"] = ("in_flight_dense_pinned: lrm_map_batch_submit / lrm_map_batch_wait, two batches on the device and one "
+                             "queued, dense result layout DMA'd into pinned caller memory")
+        pcie["host_cpu_s_per_Gbp"] = pcie["in_flight_dense_pinned"]["host_cpu_s_per_Gbp"]
+        pcie["bytes_per_batch"] = dict(h2d=int(n * stride + 4 * n), d2h_reads="reverse-strand rows only (~half of n x read_len)",
+                                       d2h_ops="used op bytes (16-byte aligned per read)", d2h_small=int(n * 60))
+        pcie["inversion_r2"] = ("BENCH_r02 had pinned (15.97) below pageable (16.90): the result scatter was on the call's critical "
+                                "path and a memcpy into hipHostMalloc'd (mapped) memory runs at 127 GB/s against 149 into pageable "
+                                "memory, 23 against 31 single-threaded reading it (profiles/r3/probes/hostlink_bench_1.jsonl); the "
+                                "dense layout removes that scatter")
 
     if rank != 0:
         if world > 1:
@@ -261,7 +382,7 @@ def main():
         return
 
     # ---- sanity of the measured batch (cheap, outside the timed region) ----------------------------
-    res = dm.results(min(n, 2000))
+    res = {k: (v[:min(n, 2000)] if hasattr(v, "__len__") else v) for k, v in full.items()}
     mapped = int(((res["meta_r"] == 1) & (res["score"] >= 0)).sum())
     truth_ok = 0
     for i in range(len(res["score"])):
@@ -310,17 +431,20 @@ def main():
         cpu["one_thread"] = dict(value=b1n / t1c / 1e9, unit="Gbp/s", cores=1,
                                  sample="first %d reads (%d bases), seed+extend, %.1f s wall" % (n1, b1n, t1c))
     # the oracle's output on the sample must equal the GPU's (same reads: the first sample_n of rank 0)
-    gres = dm.results(min(sample_n, n))
-    assert np.array_equal(gres["best"][:sample_n], best), "GPU best[] differs from the CPU oracle on the bench batch"
-    assert np.array_equal(gres["score"][:sample_n], ext["score"]), "GPU scores differ from the CPU oracle"
-    assert np.array_equal(gres["n_ops"][:sample_n], ext["n_ops"]), "GPU CIGAR lengths differ from the CPU oracle"
-    if pcie:                                     # ... and so must the results that came back through lrm_map_batch
-        assert np.array_equal(pcie_res["best"][:sample_n], best), "lrm_map_batch best[] differs from the CPU oracle"
-        assert np.array_equal(pcie_res["score"][:sample_n], ext["score"]) and np.array_equal(pcie_res["n_ops"][:sample_n], ext["n_ops"])
-        full = dm.results(n)
-        assert np.array_equal(pcie_res["best"], full["best"]) and np.array_equal(pcie_res["score"], full["score"]), \
-            "lrm_map_batch and the device-resident path disagree"
-        pcie["checked"] = "best[], score, n_ops of all %d reads equal the device-resident path; first %d equal the CPU oracle" % (n, sample_n)
+    assert np.array_equal(full["best"][:sample_n], best), "GPU best[] differs from the CPU oracle on the bench batch"
+    assert np.array_equal(full["score"][:sample_n], ext["score"]), "GPU scores differ from the CPU oracle"
+    assert np.array_equal(full["n_ops"][:sample_n], ext["n_ops"]), "GPU CIGAR lengths differ from the CPU oracle"
+    if pcie:                                     # ... and so must the results that came back through the host boundary, in every mode
+        for name, pr in pcie_res.items():
+            assert np.array_equal(pr["best"], full["best"]) and np.array_equal(pr["score"], full["score"]) \
+                and np.array_equal(pr["n_ops"], full["n_ops"]), "host boundary (%s) and the device-resident path disagree" % name
+            assert np.array_equal(pr["best"][:sample_n], best) and np.array_equal(pr["score"][:sample_n], ext["score"])
+            k0 = min(64, sample_n)
+            for i in range(k0):
+                assert pr["ops0"][i] == bytes(ext["ops"][i, :int(ext["n_ops"][i])]), "host boundary (%s): op bytes differ from the oracle" % name
+            assert np.array_equal(pr["reads0"][:k0], rs[:k0]), "host boundary (%s): reads not reverse-complemented like the oracle's" % name
+        pcie["checked"] = ("every leg: best[], score, n_ops of all %d reads equal the device-resident path, the first %d equal the CPU "
+                           "oracle; op bytes and reverse-complemented reads of the first %d reads equal the oracle's" % (n, sample_n, min(64, sample_n)))
     # algorithmic bytes per read base, counted exactly on the sample
     ce = ext["counters"]
     per_base = dict(
@@ -331,32 +455,46 @@ def main():
         cells=int(ce.cells) / sample_bases,
         seeds=ct_seed.n_seeds / sample_bases,
     )
+    # bytes the DEVICE layout must move per read base: seed_search = one 8-byte table entry per lookup + 16 bytes per rank
+    # request (counting build, whole batch) + the 2-bit read (0.25 B per base and phase round) + 12 bytes per survivor
+    # record written; vote = 8 bytes per SA row + the survivor records read back + 48 bytes per (read, phase) result
+    dev_per_base = None
+    if dev_counts and dev_counts["seeds_evaluated"]:
+        dev_per_base = dict(
+            seed_search=(8 * dev_counts["seed_table_lookups"] + 16 * dev_counts["seed_rank_requests"]) / bases + 0.25,
+            seeds=dev_counts["seeds_evaluated"] / bases,
+            table_lookups_per_seed=dev_counts["seed_table_lookups"] / dev_counts["seeds_evaluated"],
+            rank_requests_per_seed=dev_counts["seed_rank_requests"] / dev_counts["seeds_evaluated"],
+            vote=per_base["vote"] + 48.0 * (args.seed_len + 1) / Lr,
+        )
 
     # ---- per-kernel table and the roofline of the dominant kernel ----------------------------------
-    # algorithmic bytes per read base per kernel family; the three vote kernels share the SA bytes
+    # reference-layout algorithmic bytes per read base per kernel family; device-layout bytes next to them
     alg_of = {"pack2bit_kernel": per_base["pack2bit"], "seed_search_kernel": per_base["seed_search"],
               "gact_kernel": per_base["gact"], "gact_bs_kernel": per_base["gact"], "bs_pack_reads_kernel": 1.25}
-    pmc = load_pmc_summary(args, n, Lr)
+    dev_of = {"pack2bit_kernel": 1.25, "gact_kernel": per_base["gact"], "gact_bs_kernel": per_base["gact"], "bs_pack_reads_kernel": 1.25}
+    if dev_per_base:
+        dev_of["seed_search_kernel"] = dev_per_base["seed_search"]
+        dev_of["vote_kernel"] = dev_per_base["vote"]
+    pmc, pmc_file = load_pmc_summary(args, n, Lr)
 
     def kernel_table(ktimes):
         kernels, dominant = {}, None
-        vote_ms = sum(ms for name, (ms, _) in ktimes.items() if name.startswith("vote"))
         for name, (ms, launches) in ktimes.items():
             if launches == 0:
                 continue
-            alg = alg_of.get(name)
-            if name.startswith("vote") and vote_ms > 0:
-                alg = per_base["vote"] * ms / vote_ms          # SA bytes apportioned by time over the vote tiers
-            per_launch_bytes = alg * bases * args.steps / launches if alg else None
+            alg = alg_of.get(name, per_base["vote"] if name.startswith("vote") else None)
+            devb = dev_of.get(name)
             avg_ms = ms / launches
+            per_launch = lambda b: b * bases * args.steps / launches if b else None
             k = dict(ms_total=round(ms, 3), launches=launches, avg_ms=round(avg_ms, 4),
-                     algorithmic_bytes_per_launch=per_launch_bytes,
-                     achieved_GBps=(per_launch_bytes / (avg_ms * 1e-3) / 1e9) if per_launch_bytes else None)
+                     device_bytes_per_launch=per_launch(devb), reference_bytes_per_launch=per_launch(alg))
             pk = pmc.get(name.replace("gact_kernel", "gact3_kernel")) if pmc else None
             if pk:
                 k["traffic_bytes_per_launch"] = (pk["fetch_bytes"] + pk["write_bytes"]) / pk["launches_per_step"]
                 if pk.get("l2_hit") is not None and (pk["l2_hit"] + pk["l2_miss"]) > 0:
                     k["l2_hit_rate"] = pk["l2_hit"] / (pk["l2_hit"] + pk["l2_miss"])
+                    k["l2_misses_per_launch"] = pk["l2_miss"] / pk["launches_per_step"]
                 if pk.get("valu_insts"):
                     k["valu_wave_insts_per_launch"] = pk["valu_insts"] / pk["launches_per_step"]
             kernels[name] = k
@@ -366,33 +504,43 @@ def main():
 
     def roofline_of(kernels, ktimes, name):
         k = kernels[name]
-        ach = k["achieved_GBps"] or 0.0
-        r = dict(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                 traffic=k.get("traffic_bytes_per_launch"), avg_launch_ms=k["avg_ms"],
-                 algorithmic_bytes_per_launch=k["algorithmic_bytes_per_launch"])
+        sec = k["avg_ms"] * 1e-3
+        devb = k["device_bytes_per_launch"]
+        ach = devb / sec / 1e9 if devb else None
+        # frac: bytes the device layout MUST move / time / peak.  Every counted request is a request the kernel made, so
+        # frac <= traffic_frac <= 1 by construction (a request moves at least its own bytes).
+        rr = dict(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=(ach / HBM_PEAK_GBS) if ach else None,
+                  traffic=k.get("traffic_bytes_per_launch"), avg_launch_ms=k["avg_ms"], device_bytes_per_launch=devb,
+                  achieved_definition="bytes the device layout must move per launch (counting build: 8 B per seed-table lookup, "
+                                      "16 B per rank request, 8 B per SA row) / average launch time of the serialized replay")
+        if rr["traffic"]:
+            rr["traffic_frac"] = rr["traffic"] / sec / 1e9 / HBM_PEAK_GBS      # bytes really moved (64-byte lines) vs the HBM peak
+        if k.get("l2_misses_per_launch"):
+            rate = k["l2_misses_per_launch"] / sec
+            rr["random_line_rate"] = dict(achieved=rate, ceiling=RANDOM_LINES_PER_S, frac=rate / RANDOM_LINES_PER_S, unit="64-byte lines/s",
+                                          note="L2 misses per second (committed PMC pass) against the rate of independent random "
+                                               "64-byte lines this memory system delivers (tools/randline_bench.hip: 50.4 G/s over "
+                                               "64 GiB, 56 G/s inside the Infinity Cache, whatever the loads in flight)")
+        if k["reference_bytes_per_launch"]:
+            rr["reference_work_rate"] = dict(value=k["reference_bytes_per_launch"] / sec / 1e9, unit="GB/s of reference-layout bytes",
+                                             note="SURVEY 8(d)'s algorithmic bytes (16 B per lc lookup, 8 B + the scanned bwt bytes per "
+                                                  "_occ_access, from the oracle's exact counters) per second: a rate of REFERENCE work -- "
+                                                  "the device answers several of those accesses with one request, so this is not a "
+                                                  "fraction of the device's bandwidth and has no peak")
         if "valu_wave_insts_per_launch" in k:
             # integer VALU issue: one wave64 instruction per 4 cycles per SIMD, 1024 SIMDs, 2.4 GHz peak clock
             peak_ips = 1024 * 2.4e9 / 4
-            r["valu_issue_frac"] = k["valu_wave_insts_per_launch"] / (k["avg_ms"] * 1e-3) / peak_ips
-        if r["traffic"]:
-            r["traffic_frac"] = r["traffic"] / (k["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS      # bytes really moved vs the HBM peak
-        if name == "seed_search_kernel":
-            r["note"] = ("`achieved` counts the REFERENCE LAYOUT's algorithmic bytes (SURVEY 8d: 16 B per lc lookup + 8 B and the "
-                         "scanned bwt bytes per _occ_access, from the oracle's exact counters); the device answers several of "
-                         "those accesses with one request to its long seed table, so the bytes it really moves (`traffic`) are "
-                         "fewer and `frac` can reach or exceed 1 -- it is a rate of reference work against the HBM peak, not a "
-                         "claim of more than peak bandwidth; `traffic_frac` is the same ratio for the bytes really moved "
-                         "(random 64-byte lines: the kernel's time is its L2 misses / ~50 G lines per second)")
+            rr["valu_issue_frac"] = k["valu_wave_insts_per_launch"] / sec / peak_ips
         if name in ("gact_kernel", "gact_bs_kernel"):
-            r["gcups"] = per_base["cells"] * bases * args.steps / (ktimes[name][0] * 1e-3) / 1e9
-            r["note"] = ("integer DP (gact): bound by VALU issue, not by HBM or MFMA -- its HBM fraction is small by "
-                         "construction (%.1f algorithmic B/base, %.0f cells/base); see valu_issue_frac / gcups"
-                         % (per_base["gact"], per_base["cells"]))
-        return r
+            rr["gcups"] = per_base["cells"] * bases * args.steps / (ktimes[name][0] * 1e-3) / 1e9
+            rr["note"] = ("integer DP (gact): bound by VALU issue, not by HBM or MFMA -- its HBM fraction is small by "
+                          "construction (%.1f B/base, %.0f cells/base); see valu_issue_frac / gcups"
+                          % (per_base["gact"], per_base["cells"]))
+        return rr
 
     kernels, dominant = kernel_table(ktimes)
-    traffic_note = ("`traffic` = FETCH_SIZE + WRITE_SIZE per launch from the committed rocprofv3 --pmc passes of this workload "
-                    "(profiles/*/pmc_summary.json), not measured in this run; null for other workloads")
+    traffic_note = ("`traffic`, L2 misses and VALU instruction counts per launch come from the committed rocprofv3 --pmc passes of this "
+                    "workload (%s), not from this run; null for other workloads" % (pmc_file or "none for this workload"))
     isolated = None
     if ktimes_iso:
         # the roofline comes from the serialized replay: every kernel has the chip to itself, so kernel time <= step time
@@ -406,6 +554,7 @@ def main():
                         ms_per_step=iso_wall / args.steps * 1e3, value=bases * args.steps / iso_wall / 1e9,
                         kernel_ms_per_step=sum(v["ms_total"] for v in k_iso.values()) / args.steps,
                         roofline_gact=roofline_of(k_iso, ktimes_iso, "gact_bs_kernel") if "gact_bs_kernel" in k_iso else None,
+                        roofline_vote=roofline_of(k_iso, ktimes_iso, "vote_kernel") if "vote_kernel" in k_iso else None,
                         kernels=k_iso)
     else:
         roofline = roofline_of(kernels, ktimes, dominant) if dominant else None
@@ -414,26 +563,70 @@ def main():
             roofline["source"] = ("timed region, steps alternating over %d HIP streams: durations include the time a kernel "
                                   "shared the chip with kernels of other steps" % nstreams)
     total_bases = bases * world * args.steps
-    out = dict(metric="aligned Gbp/sec", value=total_bases / elapsed / 1e9, unit="Gbp/s", n_gpus=world,
+    workload = "%s synthetic reference (%d bp, 5%% planted repeats), %d x %d bp %s-profile reads per GPU" \
+               % ({ECOLI_N: "E. coli K-12 sized", CHR1_N: "human chr1 sized", GRCH38_N: "GRCh38 sized"}.get(args.ref_len, "custom"),
+                  args.ref_len, n, Lr, args.profile)
+    value = total_bases / elapsed / 1e9
+    out = dict(metric="aligned Gbp/sec", value=value, unit="Gbp/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u8/u64 integer", data="synthetic",
-               config=dict(workload="%s synthetic reference (%d bp, 5%% planted repeats), "
-                                    "%d x %d bp %s-profile reads per GPU"
-                                    % ({ECOLI_N: "E. coli K-12 sized", CHR1_N: "human chr1 sized",
-                                        GRCH38_N: "GRCh38 sized"}.get(args.ref_len, "custom"),
-                                       args.ref_len, n, Lr, args.profile),
+               value_hbm_resident=value, value_pcie_inclusive=pcie["value"] if pcie else None,
+               config=dict(workload=workload,
                            seed_len=args.seed_len, thres=args.thres, gact_T=gact[0], gact_O=gact[1], gact_W=gact[2],
-                           reads_per_gpu=n, read_len=Lr, streams=nstreams, parallelism="reads sharded, index replicated (1 RCCL bcast)"),
+                           reads_per_gpu=n, read_len=Lr, streams=nstreams, sa_sampled=args.sa_sampled or 1,
+                           parallelism="reads sharded, index replicated (1 RCCL bcast)"),
                roofline=roofline, roofline_hbm_kernel=roofline_hbm, cpu_baseline=cpu, pcie_inclusive=pcie,
-               value_note="HBM-resident: the batch is in device memory when the timed region starts (the contract's `value`); "
-                          "SURVEY 8(d)'s metric with H2D of reads and D2H of results timed is `pcie_inclusive`",
+               value_note="`value` = `value_hbm_resident`: the batch is in device memory when the timed region starts (the contract's "
+                          "definition); SURVEY 8(d)'s metric with H2D of reads and D2H of results timed is `value_pcie_inclusive` "
+                          "(details in `pcie_inclusive`)",
                kernels=kernels, isolated=isolated, streams=nstreams,
-               algorithmic_bytes_per_base=per_base, stats=stats,
+               algorithmic_bytes_per_base=dict(reference_layout=per_base, device_layout=dev_per_base), stats=stats,
                index=dict(rows=hi.length, image_bytes=int(blob.numel()), reference_s=round(t_synth, 1), build_s=round(t_build, 1),
                           pack_upload_s=round(t_pack, 1), broadcast_s=round(t_bcast, 3),
                           host_cpus=usable_cpus(), peak_rss_gb=round(peak_rss_gb(), 1)),
-               speedup_vs_cpu=(total_bases / elapsed / 1e9) / cpu["value"],
+               speedup_vs_cpu=value / cpu["value"],
                speedup_pcie_inclusive_vs_cpu=(pcie["value"] / cpu["value"]) if pcie else None)
+
+    # ---- the north-star configuration in a fresh child process (GRCh38-sized text on this one GPU) ----------------
+    if world == 1 and not args.no_grch38 and args.ref_len == ECOLI_N:
+        avail = host_gb_available()
+        spent = time.time() - t_start
+        if avail < 110:
+            out["grch38"] = dict(skipped="host memory: %.0f GB available, the index build of the 6.2 G-row text peaks at 93 GB" % avail)
+        elif spent > 170:
+            out["grch38"] = dict(skipped="time guard: the default workload took %.0f s" % spent)
+        else:
+            # everything this process holds on the device and in host RAM goes back first
+            dm.close()
+            di.close()
+            del slots, dm, di, blob, pristine, d_lens, d_reads, hi, oi, full, r, rs, ref
+            gc.collect()
+            torch.cuda.empty_cache()
+            cmd = [sys.executable, os.path.abspath(__file__), "--no-grch38", "--ref-len", str(GRCH38_N), "--steps", "10", "--warmup", "3",
+                   "--pcie-steps", "6", "--cpu-seconds", "6", "--reads", str(args.reads), "--read-len", str(args.read_len),
+                   "--seed-len", str(args.seed_len), "--thres", str(args.thres), "--gact", args.gact]
+            tg = time.time()
+            pr = None
+            try:
+                pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=args.grch38_timeout)
+                line = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+                if pr.returncode == 0 and line:
+                    g = json.loads(line[-1])
+                    for k in ("kernels", "isolated", "algorithmic_bytes_per_base"):       # the per-kernel tables stay in the child's own line
+                        if k == "isolated" and g.get(k):
+                            g[k] = dict(ms_per_step=g[k]["ms_per_step"], value=g[k]["value"], kernel_ms_per_step=g[k]["kernel_ms_per_step"],
+                                        kernel_avg_ms={kn: kv["avg_ms"] for kn, kv in g[k]["kernels"].items()})
+                        elif k == "kernels":
+                            g.pop(k, None)
+                    g["child_wall_s"] = round(time.time() - tg, 1)
+                    out["grch38"] = g
+                else:
+                    out["grch38"] = dict(failed="child exit code %d" % pr.returncode, stderr_tail=pr.stderr[-1500:])
+            except subprocess.TimeoutExpired:
+                out["grch38"] = dict(failed="child exceeded %.0f s" % args.grch38_timeout)
+            for l in (pr.stderr.splitlines()[-12:] if pr is not None else []):
+                if l.startswith("[bench]"):
+                    log("grch38 child:", l[8:])
     print(json.dumps(out), flush=True)
     if world > 1:
         tdist.barrier()

@@ -296,7 +296,13 @@ typedef struct lrm_stats {
     uint64_t vote_tier3_items;      /* ... in several passes over the workgroup table (hits > 1152) */
     uint64_t reads_decided_phase0;  /* reads whose vote passed 0.6 in phase 0 */
     uint64_t gact_tiles;
+    /* with lrm_workspace_set_counting(ws, 1): the memory requests the DEVICE layout made in the last seed call */
+    uint64_t seeds_evaluated;       /* seed positions searched */
+    uint64_t seed_table_lookups;    /* 8-byte entries of the seed tables (lchash image or long table) read */
+    uint64_t seed_rank_requests;    /* 16-byte {prefix, mask} pairs of the occ blocks read (1 or 2 per backward step) */
 } lrm_stats;
+/* Counting build of the seed kernel for the NEXT calls on this workspace (bench bookkeeping: slower, never timed). */
+int lrm_workspace_set_counting(lrm_workspace *ws, int enable);
 int lrm_workspace_stats(lrm_workspace *ws, lrm_stats *out, void *stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (bench bookkeeping).

@@ -73,7 +73,8 @@ class MapOptions(C.Structure):         # lrm_map_options
 
 class Stats(C.Structure):
     _fields_ = [("vote_tier2_items", C.c_uint64), ("vote_tier3_items", C.c_uint64),
-                ("reads_decided_phase0", C.c_uint64), ("gact_tiles", C.c_uint64)]
+                ("reads_decided_phase0", C.c_uint64), ("gact_tiles", C.c_uint64), ("seeds_evaluated", C.c_uint64),
+                ("seed_table_lookups", C.c_uint64), ("seed_rank_requests", C.c_uint64)]
 
 
 class ReadBatch(C.Structure):          # lrm_io_host.h
@@ -155,6 +156,7 @@ SYMBOLS = {
                                        C.c_uint32, C.c_void_p, GactParams, C.c_void_p, C.c_uint64, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lrm_workspace_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats), C.c_void_p]),
+    "lrm_workspace_set_counting": (C.c_int, [C.c_void_p, C.c_int]),
     "lrm_workspace_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "lrm_workspace_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lrm_kernel_name": (C.c_char_p, [C.c_int]),

@@ -958,6 +958,9 @@ extern "C" int lrm_workspace_stats(lrm_workspace *ws, lrm_stats *out, void *stre
     }
     out->reads_decided_phase0 = c.decided_phase0;
     out->gact_tiles = c.gact_tiles;
+    out->seeds_evaluated = c.reserved[3];
+    out->seed_table_lookups = c.reserved[4];
+    out->seed_rank_requests = c.reserved[5];
     return lrm_ws_take_error(ws);
 }
 
@@ -980,6 +983,12 @@ void lrm_time_end(lrm_workspace *ws, void *stream) {
     if (!ws || !ws->timing || ws->n_timed >= LRM_MAX_TIMED || !ws->ev_stop[ws->n_timed]) return;
     (void) hipEventRecord((hipEvent_t) ws->ev_stop[ws->n_timed], (hipStream_t) stream);
     ws->n_timed++;
+}
+
+extern "C" int lrm_workspace_set_counting(lrm_workspace *ws, int enable) {
+    if (!ws) { lrm_set_error("null argument"); return -1; }
+    ws->counting = enable ? 1 : 0;
+    return 0;
 }
 
 extern "C" int lrm_workspace_set_timing(lrm_workspace *ws, int enable) {

@@ -166,6 +166,7 @@ struct lrm_workspace {
     int parts;               // LRM_WS_SEED | LRM_WS_EXTEND: which scratch this workspace owns
     // optional per-kernel timing (HIP events recorded on the launch stream)
     int timing;
+    int counting;            // seed_search runs its counting build (lrm_workspace_set_counting)
     int n_timed;
     void *ev_start[LRM_MAX_TIMED], *ev_stop[LRM_MAX_TIMED];
     int ev_kernel[LRM_MAX_TIMED];

@@ -65,13 +65,16 @@ __device__ __forceinline__ uint64_t occ_lf_of(const ulonglong2 e, uint64_t loc) 
 
 // the two LF values of one backward step; after the table lookup most intervals are a handful of rows,
 // so k-1 and l usually fall into the same 64-row block and ONE 16-byte request serves both
-__device__ __forceinline__ void occ_lf2(const LrmIndexView &ix, uint32_t c, uint64_t loc_a, uint64_t loc_b,
-                                        uint64_t &ra, uint64_t &rb) {
+// (returns the number of 16-byte requests it made: 1 or 2 -- only the counting build of seed_search looks at it)
+__device__ __forceinline__ uint32_t occ_lf2(const LrmIndexView &ix, uint32_t c, uint64_t loc_a, uint64_t loc_b,
+                                            uint64_t &ra, uint64_t &rb) {
     const ulonglong2 eb = *reinterpret_cast<const ulonglong2 *>(&ix.occ[loc_b >> 6].sym[c]);
     ulonglong2 ea = eb;
-    if ((loc_a >> 6) != (loc_b >> 6)) ea = *reinterpret_cast<const ulonglong2 *>(&ix.occ[loc_a >> 6].sym[c]);
+    const bool two = (loc_a >> 6) != (loc_b >> 6);
+    if (two) ea = *reinterpret_cast<const ulonglong2 *>(&ix.occ[loc_a >> 6].sym[c]);
     ra = occ_lf_of(ea, loc_a);
     rb = occ_lf_of(eb, loc_b);
+    return two ? 2u : 1u;
 }
 
 // SA[row].  Full SA: one 8-byte gather (sa_access, fmidx.c:18-33).  Sampled SA (LRM_SA_SAMPLED=r): only rows
@@ -121,8 +124,9 @@ __device__ __forceinline__ void lc_lookup(const LrmIndexView &ix, uint64_t code,
 // win: bases j.. of the read, 2 bits each, LSB first.  Returns rr; k,l as the reference
 // leaves them (also on failure).
 // jpar: parity of the seed's read position (only the pair-line layout of the long table looks at it).
+// cnt (counting build only): cnt[0] += 8-byte table lookups, cnt[1] += 16-byte rank requests of this seed.
 __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t win, int seed_len, uint32_t jpar,
-                                             uint64_t &k, uint64_t &l) {
+                                             uint64_t &k, uint64_t &l, uint32_t *cnt = nullptr) {
     int left = seed_len - ix.hlen;
     bool looked_up = false;
     if (ix.lcl && seed_len >= ix.hl) {
@@ -142,6 +146,7 @@ __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t wi
                              : ((at >> 2) << 3) + (at & 3u);
         }
         const uint64_t e = ix.lcl[at];
+        if (cnt) cnt[0] += 1;
         if ((e >> 40) != 0xFFFFFFull) {                               // (marker: interval too long for 24 bits)
             if (e == 0) { k = 0; l = 0; return 0; }                   // dead by its hl-th base; k, l are dead values then
             k = e & ((1ull << 40) - 1ull);
@@ -153,6 +158,7 @@ __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t wi
     if (!looked_up) {
         if (left >= 0) {
             lc_lookup(ix, (win >> (2 * left)) & ((1ull << (2 * ix.hlen)) - 1ull), k, l);
+            if (cnt) cnt[0] += 1;
         } else {
             k = 1;
             l = ix.length - 1;
@@ -162,7 +168,8 @@ __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t wi
     for (int i = left - 1; i >= 0; --i) {
         uint32_t c = (uint32_t) (win >> (2 * i)) & 3u;
         uint64_t ra, rb;
-        occ_lf2(ix, c, k - 1, l, ra, rb);
+        const uint32_t nreq = occ_lf2(ix, c, k - 1, l, ra, rb);
+        if (cnt) cnt[1] += nreq;
         k = ra + 1;
         l = rb;
         if (k > l) break;
@@ -276,7 +283,10 @@ __device__ __forceinline__ uint64_t read_window(const uint64_t *__restrict__ wor
 // Measured per 1-Gbp step [r2]: E. coli-sized text 512 / 1024 / 2048 / 4096 seeds: 26.2 / 25.5 / 24.9 / 31.6 ms;
 // GRCh38-sized text 1024 / 2048 / 4096: 44.0 / 40.9 / 42.7 ms.  More resident wavefronts (1024: eight workgroups per
 // CU instead of six) do NOT help: the kernel is bound by the memory system's random-request rate, not by latency.
-template <int SS_ITEMS>
+// COUNT: the counting build (lrm_workspace_set_counting; bench bookkeeping, never in a timed region) adds up the
+// memory requests the device layout really makes -- seeds evaluated, 8-byte table lookups, 16-byte rank requests --
+// into counters->reserved[3..5].
+template <int SS_ITEMS, bool COUNT>
 __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const uint64_t *__restrict__ reads2,
                                                           uint64_t words_per_read,
                                                           const uint32_t *__restrict__ lens,
@@ -284,8 +294,12 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
                                                           int seed_len, uint32_t thres, int phase_lo, int phase_hi,
                                                           uint32_t cap_q, uint32_t blocks_per_read,
                                                           uint64_t *__restrict__ rec, uint32_t *__restrict__ recq,
-                                                          uint32_t *__restrict__ gcnt, uint32_t *__restrict__ ghits) {
+                                                          uint32_t *__restrict__ gcnt, uint32_t *__restrict__ ghits,
+                                                          LrmDevCounters *counters) {
     __shared__ uint64_t s_rec[SS_ITEMS + 64];
+    __shared__ uint32_t s_traffic[3];
+    uint32_t my_cnt[2] = {0, 0}, my_seeds = 0;
+    if (COUNT && threadIdx.x < 3) s_traffic[threadIdx.x] = 0;
     __shared__ uint32_t s_q[SS_ITEMS + 64];
     __shared__ uint32_t s_cnt[64], s_hits[64], s_base[64];
     const uint64_t read = blockIdx.x / blocks_per_read;
@@ -348,7 +362,8 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
             win = read_window(words, j);
         }
         uint64_t k, l;
-        const uint64_t rr = seed_one(ix, win, seed_len, j, k, l);
+        const uint64_t rr = seed_one(ix, win, seed_len, j, k, l, COUNT ? my_cnt : nullptr);
+        if (COUNT) my_seeds++;
         if (rr > 0 && rr < (uint64_t) thres) {
             const uint32_t slot = atomicAdd(&s_cnt[ph], 1u);
             atomicAdd(&s_hits[ph], (uint32_t) rr);
@@ -356,7 +371,9 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
             s_q[ph * cap_pp + slot] = q;
         }
     }
+    if (COUNT) { atomicAdd(&s_traffic[0], my_seeds); atomicAdd(&s_traffic[1], my_cnt[0]); atomicAdd(&s_traffic[2], my_cnt[1]); }
     __syncthreads();
+    if (COUNT && tid < 3) atomicAdd(&counters->reserved[3 + tid], (unsigned long long) s_traffic[tid]);
     if (tid < np) {
         const uint32_t c = s_cnt[tid];
         if (c) {
@@ -1006,10 +1023,13 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
         uint64_t blocks = n * bpr;
         if (blocks > 0x7fffffffull) { lrm_set_error("seed_search grid too large: split the batch"); return -1; }
         lrm_time_begin(ws, LRM_K_SEED_SEARCH, stream);
-        auto sk = ss_items == 1024u ? seed_search_kernel<1024> : ss_items == 4096u ? seed_search_kernel<4096> : seed_search_kernel<2048>;
+        auto sk = ws->counting ? seed_search_kernel<2048, true>
+                               : ss_items == 1024u ? seed_search_kernel<1024, false> : ss_items == 4096u ? seed_search_kernel<4096, false> : seed_search_kernel<2048, false>;
+        if (ws->counting) bpr = (uint32_t) (((uint64_t) np * cap_q + 2047) / 2048);
+        if (ws->counting) blocks = n * bpr;
         hipLaunchKernelGGL(sk, dim3((uint32_t) blocks), dim3(256), 0, stream, idx->view,
                            ws->d_reads2, wpr, d_lens, dec, n, (int) seed_len, thres, lo, hi, cap_q, bpr,
-                           ws->d_rec, ws->d_recq, ws->d_cnt, ws->d_hcount);
+                           ws->d_rec, ws->d_recq, ws->d_cnt, ws->d_hcount, ws->d_counters);
         lrm_time_end(ws, stream);
         uint64_t items = n * (uint64_t) np;
         uint64_t vblocks = (items + vg - 1) / vg;

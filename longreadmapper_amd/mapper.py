@@ -217,7 +217,13 @@ class DeviceMapper:
         st = capi.Stats()
         check(lib.lrm_workspace_stats(self.ws, C.byref(st), self._stream()), "lrm_workspace_stats")
         return dict(vote_tier2_items=int(st.vote_tier2_items), vote_tier3_items=int(st.vote_tier3_items),
-                    reads_decided_phase0=int(st.reads_decided_phase0), gact_tiles=int(st.gact_tiles))
+                    reads_decided_phase0=int(st.reads_decided_phase0), gact_tiles=int(st.gact_tiles),
+                    seeds_evaluated=int(st.seeds_evaluated), seed_table_lookups=int(st.seed_table_lookups),
+                    seed_rank_requests=int(st.seed_rank_requests))
+
+    def set_counting(self, enable=True):
+        """The next seed calls run the counting build of the seed kernel (stats(): requests of the device layout)."""
+        check(lib.lrm_workspace_set_counting(self.ws, int(enable)), "lrm_workspace_set_counting")
 
     def set_timing(self, enable=True):
         check(lib.lrm_workspace_set_timing(self.ws, int(enable)), "lrm_workspace_set_timing")
