@@ -109,7 +109,12 @@ typedef struct lrm_index_options {
     int32_t lc_pair;           /* layout of the long table: -1 automatic (pair-line), 0 plain, 1 pair-line */
     uint32_t lcx_threshold;    /* 0: default (2^24 - 1); lchash intervals of at least this many rows go through the side
                                   table (tests) */
-    uint32_t reserved[10];
+    uint32_t lc_entry_bytes;   /* entries of the long table: 0 automatic, 8, or 5 (pair-line layout only: 40 bytes per
+                                  (k-1)-mer instead of 64 -- pair-line 17-mers of a GRCh38-sized text in 160 GiB; counts that
+                                  do not fit the 40 - ceil(log2(rows)) count bits go through a side hash table) */
+    uint32_t lc_count_bits;    /* tests: count bits of the 5-byte entries (0: 40 - ceil(log2(rows))); a small value sends
+                                  ordinary repeats through the side hash table */
+    uint32_t reserved[8];
 } lrm_index_options;
 void lrm_index_options_init(lrm_index_options *o);
 

@@ -145,7 +145,29 @@ __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t wi
             at = (jpar & 1u) ? ((at & smask) << 3) + 4u + (at >> (2 * (ix.hl - 1)))
                              : ((at >> 2) << 3) + (at & 3u);
         }
-        const uint64_t e = ix.lcl[at];
+        uint64_t e;
+        if (ix.lcl_kbits) {
+            // 5-byte entries (pair-line layout only: 40 bytes per (hl-1)-mer): k in the low kbits bits, the count above;
+            // a count of all ones sends the hl-mer to the side hash table (an 8-byte entry per such hl-mer)
+            uint64_t v;
+            __builtin_memcpy(&v, reinterpret_cast<const uint8_t *>(ix.lcl) + at * 5, 8);     // one unaligned 8-byte request
+            v &= (1ull << 40) - 1ull;
+            const uint64_t c5 = v >> ix.lcl_kbits, cmax = (1ull << (40 - ix.lcl_kbits)) - 1ull;
+            e = v == 0 ? 0ull : (v & ((1ull << ix.lcl_kbits) - 1ull)) | (c5 << 40);
+            if (c5 == cmax) {
+                const uint64_t code = (win >> (2 * left2)) & ((1ull << (2 * ix.hl)) - 1ull);
+                uint64_t slot = (code * 0x9E3779B97F4A7C15ull) >> 20 & ix.lclx_mask;
+                for (;;) {                                                // the hl-mer is in the table: the packer put it there
+                    const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(ix.lclx + 2 * slot);
+                    if (x.x == code + 1) { e = x.y; break; }
+                    if (x.x == 0) { e = 0xFFFFFFull << 40; break; }       // (never: defensive, takes the reference's path)
+                    slot = (slot + 1) & ix.lclx_mask;
+                }
+                if (cnt) cnt[0] += 1;
+            }
+        } else {
+            e = ix.lcl[at];
+        }
         if (cnt) cnt[0] += 1;
         if ((e >> 40) != 0xFFFFFFull) {                               // (marker: interval too long for 24 bits)
             if (e == 0) { k = 0; l = 0; return 0; }                   // dead by its hl-th base; k, l are dead values then
@@ -199,62 +221,123 @@ __device__ __forceinline__ uint64_t lcl_entry(const LrmIndexView &ix, int hl, ui
 
 // Long table, one lane per slot.  PLAIN layout: slot = hl-mer code.  PAIR-LINE layout (see seed_one): line S (an
 // (hl-1)-mer), slot a < 4: the entry of a.S; slot 4 + b: the entry of S.b -- every hl-mer is stored twice (once as a
-// left, once as a right extension of an (hl-1)-mer): 16 bytes per hl-mer.
-__global__ __launch_bounds__(256) void lcl_build_kernel(LrmIndexView ix, int hl, int pair, uint64_t *__restrict__ out,
-                                                        uint64_t slot0) {
+// left, once as a right extension of an (hl-1)-mer): 16 bytes per hl-mer, or 10 with 5-byte entries (kbits > 0).
+// 5-byte entries whose count does not fit go to `ovf` ({code, entry} pairs, appended once per hl-mer: from its
+// left-extension slot) for the side hash table.
+__global__ __launch_bounds__(256) void lcl_build_kernel(LrmIndexView ix, int hl, int pair, int kbits, uint64_t *__restrict__ out,
+                                                        uint64_t slot0, uint64_t *__restrict__ ovf, uint64_t ovf_cap,
+                                                        unsigned long long *__restrict__ n_ovf) {
     const uint64_t slot = slot0 + (uint64_t) blockIdx.x * 256 + threadIdx.x;
     uint64_t code = slot;
+    uint32_t w = 0;
     if (pair) {
         const uint64_t S = slot >> 3;
         if (S >= (1ull << (2 * (hl - 1)))) return;
-        const uint32_t w = (uint32_t) slot & 7u;
+        w = (uint32_t) slot & 7u;
         code = w < 4 ? ((S << 2) | w) : (S | ((uint64_t) (w - 4) << (2 * (hl - 1))));
     } else if (code >= (1ull << (2 * hl))) {
         return;
     }
-    out[slot] = lcl_entry(ix, hl, code);
+    const uint64_t e = lcl_entry(ix, hl, code);
+    if (!kbits) { out[slot] = e; return; }
+    const uint64_t cmax = (1ull << (40 - kbits)) - 1ull, c = e >> 40;
+    uint64_t v = e & ((1ull << 40) - 1ull);                            // k (< 2^kbits)
+    if (e != 0) {
+        if (c < cmax) v |= c << kbits;
+        else {
+            v |= cmax << kbits;
+            if (w < 4) {
+                const unsigned long long at = atomicAdd(n_ovf, 1ull);
+                if (at < ovf_cap) { ovf[2 * at] = code; ovf[2 * at + 1] = e; }
+            }
+        }
+    }
+    uint8_t *p = reinterpret_cast<uint8_t *>(out) + slot * 5;
+    const uint32_t lo = (uint32_t) v;
+    __builtin_memcpy(p, &lo, 4);
+    p[4] = (uint8_t) (v >> 32);
 }
 
-// The long seed table.  seed_search's time is its L2 misses divided by ~50 G random 64-byte lines per second, and
-// the first lookup of a seed is a miss whatever the text, so the table is (a) as long as HBM allows -- the longer the
-// k-mer, the more noisy seeds die in the lookup instead of one random step later -- and (b) in the pair-line layout,
-// where the lookups of two neighbouring read positions share a line.  Measured on 100 k x 10 kbp ONT reads, ms per Gbp
-// [r2]: E. coli-sized text plain 13-mers 24.5, pair-line 13 / 14 / 15 / 16-mers 19.2 / 18.5 / 17.6 / 15.6;
-// chr1-sized text plain 16 28.4, pair-line 16 20.3; GRCh38-sized text plain 16 40.6, plain 17 (128 GiB) 32.4,
-// pair-line 16 (64 GiB) 30.2.
-// Automatic choice: pair-line 16-mers (64 GiB) when that leaves 64 GiB of HBM free, else 15 (16 GiB, leaving 32),
-// 14 (4 GiB, leaving 8), 13 (1 GiB).  LRM_LC_LONG = 0 (off) | 13..17, LRM_LC_PAIR = 0 | 1 override.  A table that
-// cannot be allocated is skipped: results never depend on it.  Cost at upload [r2]: 16 GiB and below ~10 ms, the 64 GiB
+__global__ __launch_bounds__(256) void lclx_build_kernel(const uint64_t *__restrict__ ovf, uint64_t n, uint64_t *__restrict__ table, uint64_t mask) {
+    const uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t code = ovf[2 * i], e = ovf[2 * i + 1];
+    uint64_t slot = (code * 0x9E3779B97F4A7C15ull) >> 20 & mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS((unsigned long long *) &table[2 * slot], 0ull, (unsigned long long) (code + 1));
+        if (prev == 0ull || prev == code + 1) { table[2 * slot + 1] = e; return; }
+        slot = (slot + 1) & mask;
+    }
+}
+
+// The long seed table.  seed_search's time is its L2 misses divided by ~50 G random 64-byte lines per second
+// (tools/randline_bench.hip pins that rate independently), and the first lookup of a seed is a miss whatever the text,
+// so the table is (a) as long as HBM allows -- the longer the k-mer, the more noisy seeds die in the lookup instead of one
+// random step later -- and (b) in the pair-line layout, where the lookups of two neighbouring read positions share a
+// line.  Measured on 100 k x 10 kbp ONT reads, ms per Gbp [r2]: E. coli-sized text plain 13-mers 24.5, pair-line
+// 13 / 14 / 15 / 16-mers 19.2 / 18.5 / 17.6 / 15.6; chr1-sized text plain 16 28.4, pair-line 16 20.3; GRCh38-sized text
+// plain 16 40.6, plain 17 (128 GiB) 32.4, pair-line 16 (64 GiB) 30.2.
+// Automatic choice: texts of >= 2^32 rows (every 16-mer occurs: the lookup decides nothing there) take pair-line 17-mers
+// with 5-BYTE entries (160 GiB) when that leaves 40 GiB of HBM free; otherwise pair-line 16-mers with 8-byte entries
+// (64 GiB) when that leaves 64 GiB free, else 15 (16 GiB, leaving 32), 14 (4 GiB, leaving 8), 13 (1 GiB).
+// lrm_index_options lc_long = 0 (off) | 13..17, lc_pair = 0 | 1, lc_entry_bytes = 5 | 8 override.  A table that cannot
+// be allocated is skipped: results never depend on it.  Cost at upload [r2]: 16 GiB and below ~10 ms, the 64 GiB
 // table 0.65 s (2 s when the memory was freed a moment ago) -- repaid after a few hundred Gbp of reads, so callers that
 // know their run is short cap the length (lrm_index_options.lc_long_max; lrm_accaln does it from the size of the reads
 // file).
-
 int lrm_lcl_prepare_index(lrm_index *idx) {
     const uint64_t L = idx->view.length;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); free_b = 0; }
-    int hl = 13, pair = 1;
-    static const struct { int hl; uint64_t spare; } ladder[] = {{16, 64ull << 30}, {15, 32ull << 30}, {14, 8ull << 30}};
+    int hl = 13, pair = 1, ebytes = 8;
+    int kbits = 1;
+    while ((1ull << kbits) < L) ++kbits;
+    static const struct { int hl, ebytes; uint64_t spare, min_rows; } ladder[] = {
+        {17, 5, 40ull << 30, 1ull << 32}, {16, 8, 64ull << 30, 0}, {15, 8, 32ull << 30, 0}, {14, 8, 8ull << 30, 0}};
     for (const auto &c : ladder)
-        if ((uint64_t) free_b >= (16ull << (2 * c.hl)) + c.spare) { hl = c.hl; break; }
+        if (L >= c.min_rows && kbits <= 36 && (uint64_t) free_b >= (2ull * c.ebytes << (2 * c.hl)) + c.spare) { hl = c.hl; ebytes = c.ebytes; break; }
     const LrmIndexTune &tu = idx->itune;
-    if (tu.lc_long_max >= 13 && hl > tu.lc_long_max) hl = tu.lc_long_max;      // the caller expects a short run
-    if (tu.lc_long >= 0) hl = tu.lc_long;
+    if (tu.lc_long_max >= 13 && hl > tu.lc_long_max) { hl = tu.lc_long_max; ebytes = 8; }      // the caller expects a short run
+    if (tu.lc_long >= 0) { if (tu.lc_long != hl) ebytes = 8; hl = tu.lc_long; }
     if (tu.lc_pair >= 0) pair = tu.lc_pair != 0;
+    if (tu.lc_entry_bytes) ebytes = tu.lc_entry_bytes;
+    if (!pair || kbits > 36) ebytes = 8;                               // (>= 4 count bits; the plain layout keeps aligned 8-byte entries)
+    if (tu.lc_count_bits && 40 - tu.lc_count_bits >= kbits) kbits = 40 - tu.lc_count_bits;       // (tests: few count bits force the side table)
     if (hl <= idx->view.hlen || hl > 17 || L < 2) return 0;
-    uint64_t *d = nullptr;
+    uint64_t *d = nullptr, *ovf = nullptr, *tab = nullptr;
+    unsigned long long *n_ovf = nullptr;
     const uint64_t slots = (pair ? 2ull : 1ull) << (2 * hl);
-    if (hipMalloc(&d, slots * 8) != hipSuccess) { (void) hipGetLastError(); return 0; }     // no room: the reference's table alone
+    const uint64_t ovf_cap = ebytes == 5 ? (slots / 64 < (64ull << 20) ? slots / 64 + 1024 : (64ull << 20)) : 0;
+    auto give_up = [&]() { if (d) (void) hipFree(d); if (ovf) (void) hipFree(ovf); if (tab) (void) hipFree(tab); if (n_ovf) (void) hipFree(n_ovf); (void) hipGetLastError(); };
+    if (hipMalloc(&d, slots * (uint64_t) ebytes + 16) != hipSuccess) { d = nullptr; give_up(); return 0; }     // no room: the reference's table alone
+    if (ebytes == 5 && (hipMalloc(&ovf, ovf_cap * 16) != hipSuccess || hipMalloc(&n_ovf, 8) != hipSuccess || hipMemset(n_ovf, 0, 8) != hipSuccess)) { give_up(); return 0; }
     const uint64_t chunk = 1ull << 22;                                // 2^30 threads per launch (grid limit 2^32)
     for (uint64_t b0 = 0, blocks = slots / 256; b0 < blocks; b0 += chunk) {
         const uint64_t nb = blocks - b0 < chunk ? blocks - b0 : chunk;
-        hipLaunchKernelGGL(lcl_build_kernel, dim3((uint32_t) nb), dim3(256), 0, 0, idx->view, hl, pair, d, b0 * 256);
+        hipLaunchKernelGGL(lcl_build_kernel, dim3((uint32_t) nb), dim3(256), 0, 0, idx->view, hl, pair, ebytes == 5 ? kbits : 0, d, b0 * 256,
+                           ovf, ovf_cap, n_ovf);
     }
-    if (hipDeviceSynchronize() != hipSuccess) { (void) hipFree(d); lrm_set_error("long lc table build failed"); return -1; }
+    if (hipDeviceSynchronize() != hipSuccess) { give_up(); lrm_set_error("long lc table build failed"); return -1; }
+    uint64_t mask = 0;
+    if (ebytes == 5) {
+        unsigned long long n = 0;
+        if (hipMemcpy(&n, n_ovf, 8, hipMemcpyDeviceToHost) != hipSuccess || n > ovf_cap) { give_up(); return 0; }   // (too many: the lchash image alone)
+        uint64_t tslots = 1024;
+        while (tslots < 2 * n) tslots <<= 1;
+        mask = tslots - 1;
+        if (hipMalloc(&tab, tslots * 16) != hipSuccess || hipMemset(tab, 0, tslots * 16) != hipSuccess) { give_up(); return 0; }
+        if (n) hipLaunchKernelGGL(lclx_build_kernel, dim3((uint32_t) ((n + 255) / 256)), dim3(256), 0, 0, ovf, (uint64_t) n, tab, mask);
+        if (hipDeviceSynchronize() != hipSuccess) { give_up(); lrm_set_error("long lc side table build failed"); return -1; }
+        (void) hipFree(ovf); (void) hipFree(n_ovf);
+    }
     idx->d_lcl = d;
+    idx->d_lclx = tab;
     idx->view.lcl = d;
     idx->view.hl = hl;
     idx->view.lcl_pair = pair;
+    idx->view.lcl_kbits = ebytes == 5 ? kbits : 0;
+    idx->view.lclx = tab;
+    idx->view.lclx_mask = mask;
     return 0;
 }
 

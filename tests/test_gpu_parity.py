@@ -121,7 +121,7 @@ def test_gact_rejects_unsupported_params(gpu):
         assert rc < 0 and b"unsupported GACT" in capi.lib.lrm_last_error()
 
 
-@pytest.mark.parametrize("long_table", ["0", "auto", "16", "13-plain", "14"])
+@pytest.mark.parametrize("long_table", ["0", "auto", "16", "13-plain", "14", "15-5byte", "14-5byte-side"])
 @pytest.mark.parametrize("name", ["clean-1k", "ont-2k", "pacbio-3k-h12", "ragged", "seed12", "seed32",
                                   "seed-below-hlen", "repeats-ties"])
 def test_seed_search_per_seed(dev_indexes, gpu, name, long_table):
@@ -130,13 +130,15 @@ def test_seed_search_per_seed(dev_indexes, gpu, name, long_table):
     pair-line 16-mers when 128 GiB of HBM are free, shorter k-mers otherwise; "13-plain": the plain layout) a seed that
     dies inside its last hl bases reports k = l = 0 -- rr = 0 either way, and the reference never reads k, l of such
     a seed (alnmain.c:357-366)."""
-    if long_table in ("16", "13-plain", "14") and name not in ("ont-2k", "seed32", "ragged"):
+    if long_table not in ("0", "auto") and name not in ("ont-2k", "seed32", "ragged", "repeats-ties"):
         pytest.skip("explicit table variants are built for three scenarios only")
     sc, di, oi = dev_indexes(name)
     own = None
     if long_table != "auto":
         own = di = index.DeviceIndex.upload(sc["hi"], gpu, lc_long=int(long_table.split("-")[0]),
-                                            lc_pair=0 if long_table.endswith("-plain") else None)
+                                            lc_pair=0 if long_table.endswith("-plain") else None,
+                                            lc_entry_bytes=5 if "5byte" in long_table else None,      # 40 bytes per (k-1)-mer
+                                            lc_count_bits=2 if long_table.endswith("-side") else None)  # counts >= 3: side hash table
     s = sc["seed_len"]
     for i in range(0, len(sc["lens"]), 5):
         ln = int(sc["lens"][i])
@@ -174,11 +176,13 @@ def test_seed_batch_vs_oracle(dev_indexes, gpu, name):
     for f in ("key", "val", "bucket"):
         assert np.array_equal(got[f], want[f]), (name, f, np.nonzero(got[f] != want[f])[0][:10])
     # the same through the long seed table (what large texts use automatically)
-    d2 = index.DeviceIndex.upload(sc["hi"], gpu, lc_long=14)
-    got = mapper.seed_batch(d2, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
-    d2.close()
-    for f in ("key", "val", "bucket"):
-        assert np.array_equal(got[f], want[f]), (name, f, "long table")
+    for tag, opts in (("long table", dict(lc_long=14)), ("5-byte long table", dict(lc_long=15, lc_entry_bytes=5)),
+                      ("5-byte long table, side hash table", dict(lc_long=14, lc_entry_bytes=5, lc_count_bits=2))):
+        d2 = index.DeviceIndex.upload(sc["hi"], gpu, **opts)
+        got = mapper.seed_batch(d2, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+        d2.close()
+        for f in ("key", "val", "bucket"):
+            assert np.array_equal(got[f], want[f]), (name, f, tag)
     if name == "clean-1k":
         assert (phases == 1).mean() > 0.7          # exercised the phase-0 early decision
     if name == "ont-2k":
