@@ -305,6 +305,7 @@ typedef struct lrm_stats {
     uint64_t seeds_evaluated;       /* seed positions searched */
     uint64_t seed_table_lookups;    /* 8-byte entries of the seed tables (lchash image or long table) read */
     uint64_t seed_rank_requests;    /* 16-byte {prefix, mask} pairs of the occ blocks read (1 or 2 per backward step) */
+    uint64_t vote_redo_items;       /* (read, phase) items the fast vote kernel left to the exact one */
 } lrm_stats;
 /* Counting build of the seed kernel for the NEXT calls on this workspace (bench bookkeeping: slower, never timed). */
 int lrm_workspace_set_counting(lrm_workspace *ws, int enable);

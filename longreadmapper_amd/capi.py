@@ -74,7 +74,7 @@ class MapOptions(C.Structure):         # lrm_map_options
 class Stats(C.Structure):
     _fields_ = [("vote_tier2_items", C.c_uint64), ("vote_tier3_items", C.c_uint64),
                 ("reads_decided_phase0", C.c_uint64), ("gact_tiles", C.c_uint64), ("seeds_evaluated", C.c_uint64),
-                ("seed_table_lookups", C.c_uint64), ("seed_rank_requests", C.c_uint64)]
+                ("seed_table_lookups", C.c_uint64), ("seed_rank_requests", C.c_uint64), ("vote_redo_items", C.c_uint64)]
 
 
 class ReadBatch(C.Structure):          # lrm_io_host.h

@@ -71,7 +71,7 @@ static const char *const k_env_names[] = {
     "LRM_SA_SAMPLED", "LRM_LC_LONG", "LRM_LC_PAIR", "LRM_LC_BYTES", "LRM_LCX_THRESHOLD",                        // index
     "LRM_GACT_IMPL", "LRM_SEED_ROUNDS", "LRM_HOST_DENSE", "LRM_HOST_SLICE", "LRM_HOST_SUBS",
     "LRM_HOST_GROUP", "LRM_BS_WAVES", "LRM_SS_ITEMS", "LRM_VOTE_VG", "LRM_VOTE_T1", "LRM_VOTE_U", "LRM_VOTE_LOAD",
-    "LRM_HOST_EXT_STREAMS", "LRM_HOST_SEED_STREAMS", "LRM_HOST_VERBOSE", "LRM_VOTE_SORT", "LRM_HOST_SLOTS"};
+    "LRM_HOST_EXT_STREAMS", "LRM_HOST_SEED_STREAMS", "LRM_HOST_VERBOSE", "LRM_VOTE_FAST", "LRM_HOST_SLOTS"};
 static_assert(sizeof(k_env_names) / sizeof(k_env_names[0]) <= LrmEnv::MAXV, "LrmEnv too small");
 
 void lrm_env_snapshot(LrmEnv *e) {
@@ -132,7 +132,7 @@ void lrm_resolve_map_tune(const lrm_map_options *opt, const LrmEnv &env, LrmMapT
     t->gact_impl = o.gact_impl; t->seed_rounds = o.seed_rounds;
     t->slice_reads = o.slice_reads; t->sub_batches = o.sub_batches; t->group_subs = o.group_subs; t->bs_waves = o.bs_waves;
     // measured defaults of the kernel knobs (tools/seed_probe.py sweeps them through the environment)
-    t->ss_items = 2048; t->vote_vg = 16; t->vote_t1 = LRM_VOTE_T1_LIMIT; t->vote_u = 2; t->vote_load = 50;
+    t->ss_items = 2048; t->vote_vg = 16; t->vote_t1 = LRM_VOTE_T1_LIMIT; t->vote_u = 2; t->vote_load = 50; t->vote_fast = 1;
     t->ext_streams = 2; t->seed_streams = 2;
     long long v;
     if (env.get("LRM_GACT_IMPL", &v)) t->gact_impl = (int) v;
@@ -147,6 +147,7 @@ void lrm_resolve_map_tune(const lrm_map_options *opt, const LrmEnv &env, LrmMapT
     if (env.get("LRM_VOTE_T1", &v) && v >= 0 && v <= LRM_VOTE_T1_LIMIT) t->vote_t1 = (uint32_t) v;
     if (env.get("LRM_VOTE_U", &v)) t->vote_u = (uint32_t) v;
     if (env.get("LRM_VOTE_LOAD", &v) && v >= 10 && v <= 95) t->vote_load = (uint32_t) v;
+    if (env.get("LRM_VOTE_FAST", &v)) t->vote_fast = v != 0;
     if (env.get("LRM_HOST_EXT_STREAMS", &v) && v >= 1 && v <= 4) t->ext_streams = (int) v;
     if (env.get("LRM_HOST_SEED_STREAMS", &v) && v >= 1 && v <= 3) t->seed_streams = (int) v;
     if (env.get("LRM_HOST_VERBOSE", &v)) t->verbose = v != 0;
@@ -809,7 +810,7 @@ extern "C" void lrm_workspace_free(lrm_workspace *ws) {
     if (!ws) return;
     (void) hipSetDevice(ws->device);
     (void) hipFree(ws->d_reads2); (void) hipFree(ws->d_rec); (void) hipFree(ws->d_phase); (void) hipFree(ws->d_decided);
-    (void) hipFree(ws->d_hcount); (void) hipFree(ws->d_counters); (void) hipFree(ws->d_recq); (void) hipFree(ws->d_cnt); (void) hipFree(ws->d_kc_key); (void) hipFree(ws->d_kc_ord);
+    (void) hipFree(ws->d_hcount); (void) hipFree(ws->d_counters); (void) hipFree(ws->d_recq); (void) hipFree(ws->d_cnt); (void) hipFree(ws->d_kc_key); (void) hipFree(ws->d_kc_ord); (void) hipFree(ws->d_redo);
     (void) hipFree(ws->d_qpl); (void) hipFree(ws->d_rflags);
     (void) hipFree(ws->d_ckpt); (void) hipFree(ws->d_codes); (void) hipFree(ws->d_ncodes);
     if (ws->h_err) (void) hipHostFree((void *) ws->h_err);
@@ -857,6 +858,7 @@ int lrm_workspace_create_parts(lrm_workspace **out, lrm_index *idx, uint64_t n_m
         {(void **) &ws->d_cnt, n_max * (uint64_t) ws->P * 4, LRM_WS_SEED},
         {(void **) &ws->d_kc_key, (uint64_t) LRM_VOTE_GRID * LRM_VOTE_KC_CAP * 8, LRM_WS_SEED},
         {(void **) &ws->d_kc_ord, (uint64_t) LRM_VOTE_GRID * LRM_VOTE_KC_CAP * 4, LRM_WS_SEED},
+        {(void **) &ws->d_redo, n_max * (uint64_t) ws->P * 8, LRM_WS_SEED},
         {(void **) &ws->d_phase, n_max * (uint64_t) ws->P * sizeof(LrmPhaseRes), LRM_WS_SEED},
         {(void **) &ws->d_decided, n_max, LRM_WS_SEED},
         {(void **) &ws->d_hcount, n_max * (uint64_t) ws->P * 4, LRM_WS_SEED},
@@ -962,6 +964,7 @@ extern "C" int lrm_workspace_stats(lrm_workspace *ws, lrm_stats *out, void *stre
     }
     out->reads_decided_phase0 = c.decided_phase0;
     out->gact_tiles = c.gact_tiles;
+    out->vote_redo_items = c.vote_redo_n[0] + c.vote_redo_n[1];
     out->seeds_evaluated = c.reserved[3];
     out->seed_table_lookups = c.reserved[4];
     out->seed_rank_requests = c.reserved[5];

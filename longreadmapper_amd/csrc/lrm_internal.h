@@ -100,7 +100,7 @@ struct LrmIndexTune {
 struct LrmMapTune {
     int dense, gact_impl, seed_rounds;
     uint32_t slice_reads, sub_batches, group_subs, bs_waves;
-    uint32_t ss_items, vote_vg, vote_t1, vote_u, vote_load;      // kernel tuning (environment only; measured defaults)
+    uint32_t ss_items, vote_vg, vote_t1, vote_u, vote_load, vote_fast;      // kernel tuning (environment only; measured defaults)
     uint32_t t3_limit, t3_slots;                                 // lrm_debug_set_vote_limits (tests)
     int ext_streams, seed_streams, verbose;
 };
@@ -143,6 +143,8 @@ struct LrmDevCounters {
     unsigned long long decided_phase0;
     unsigned long long gact_tiles;
     unsigned long long pad[2];
+    unsigned long long vote_fast_ticket[2];   // per seeding round: ticket of vote_fast_kernel,
+    unsigned long long vote_redo_n[2];        //   items it left to the exact kernel
 };
 // Error word of a workspace: ONE dword of host-coherent pinned memory that kernels set with a plain store (bit 0:
 // vote table overflow in the multi-pass tier).  It is never cleared by a launch, so an error raised by any
@@ -156,6 +158,7 @@ struct LrmDevCounters {
 #endif
 #define LRM_VOTE_T3_LIMIT (LRM_VOTE_T3_SLOTS * 3 / 4)
 #define LRM_VOTE_GRID 1536        // resident workgroups of the vote kernel (6 per CU)
+#define LRM_VOTE_FAST_GRID 1280   // ... of the fast vote kernel (5 per CU)
 #define LRM_VOTE_KC_CAP 16384     // hits per workgroup whose keys the multi-pass items keep between passes (12 B each)
 
 enum LrmKernelId { LRM_K_PACK2BIT = 0, LRM_K_SEED_SEARCH, LRM_K_VOTE, LRM_K_DECIDE,
@@ -189,6 +192,7 @@ struct lrm_workspace {
     uint32_t *d_cnt;         // survivors per (read, phase)
     uint64_t *d_kc_key;      // vote kernel: per-workgroup scratch of the keys of multi-pass items (LRM_VOTE_GRID x LRM_VOTE_KC_CAP)
     uint32_t *d_kc_ord;      //              ... and their order keys
+    uint64_t *d_redo;        // items the fast vote kernel left to the exact one (n_max * P)
     LrmPhaseRes *d_phase;    // n_max * P
     uint8_t *d_decided;      // n_max
     uint32_t *d_hcount;      // SA hits (sum of rr) per (read, phase): routes an item to its vote-table tier

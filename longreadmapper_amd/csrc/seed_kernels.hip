@@ -894,6 +894,205 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
     if (tid == 0) write_phase(out, best);
 }
 
+// ---- fast path: one wavefront per item, repeat-only buckets never enter the table ------------------------------------------
+// On a text with interspersed repeats most hits of an item come from a few REPEAT seeds (rr up to thres - 1 hits each)
+// and land in buckets of their own, one or two votes each: on the bench workload 85 % of all hits, and what pushes an
+// item from the 256-slot wavefront table into the workgroup tier and its passes.  They cannot win.  The vote's output is
+// the top entry and the COUNT of the second (alnmain.c:374-388 reads cand[0] and cand[1].val only), so:
+//   A  the hits of the UNIQUE seeds (rr == 1; at most one per survivor) are inserted as before -- table T;
+//   B  a hit of a repeat seed is looked up in T with plain reads: present -> counted (count, min key, first-seen
+//      order: exactly what an insert would have done); absent -> it belongs to a bucket made of repeat hits only, and
+//      only a 16-bit counter of a small SKETCH (indexed by a hash of the bucket) is incremented -- no compare-and-swap,
+//      no probe chain, no table space;
+//   C  with t2 = the second-highest count in T and M = the largest sketch counter (>= the count of every repeat-only
+//      bucket): if M < t2 no repeat-only bucket reaches the top two, and the top two of T are the item's result, bit for
+//      bit.  Otherwise (few true hits, or a read made of repeats) the item goes on a list for the exact kernel above.
+// The table only ever holds buckets of unique seeds (<= survivors <= T1_LIMIT), so an item needs one pass whatever its
+// hit count, and a wavefront stages its repeat seeds 64 survivors at a time.  Items with more than T1_LIMIT survivors go
+// to the exact kernel as well.
+#define FAST_SK_WORDS 512                    // 1024 16-bit counters per wavefront
+struct FastLds {
+    uint64_t key[T1_SLOTS];
+    uint64_t cf[T1_SLOTS];
+    uint64_t srec[64];
+    uint32_t off[64 + 4];
+    uint32_t sq[64];
+    uint32_t sketch[FAST_SK_WORDS];
+};
+
+// B: returns true if the bucket is in the table (and has been counted)
+__device__ __forceinline__ bool vote_count_if_present(const VoteTable &t, uint64_t key, uint32_t order, uint32_t hash) {
+    const uint64_t bucket = key >> 4;
+    uint32_t slot = (uint32_t) (((uint64_t) hash * t.slots) >> 32);
+    for (uint32_t probe = 0; probe < t.slots; ++probe) {
+        const uint64_t prev = t.key[slot];
+        if (prev == EMPTY_KEY) return false;                              // (no deletions: an empty slot ends the chain)
+        if ((prev >> 4) == bucket) {
+            if (key < prev) atomicMin((unsigned long long *) &t.key[slot], (unsigned long long) key);
+            uint32_t *cf = reinterpret_cast<uint32_t *>(&t.cf[slot]);
+            atomicAdd(cf + 1, 1u);
+            atomicMax(cf, 0xFFFFFFFFu - order);
+            return true;
+        }
+        slot = slot + 1 == t.slots ? 0 : slot + 1;
+    }
+    return false;
+}
+
+template <int VOTE_U>
+__device__ __forceinline__ void fast_hits(const LrmIndexView &ix, const VoteTable &t, FastLds &L, uint32_t cnt, uint32_t total,
+                                          uint32_t iter, uint32_t P, uint32_t tbits, uint32_t lane) {
+    for (uint32_t hb = 0; hb < total; hb += 64 * VOTE_U) {
+        uint64_t v[VOTE_U];
+        uint32_t ss[VOTE_U], tt[VOTE_U];
+#pragma unroll
+        for (int u = 0; u < VOTE_U; ++u) {
+            const uint32_t h = hb + (uint32_t) u * 64 + lane;
+            v[u] = 0; ss[u] = 0; tt[u] = 0;
+            if (h < total) {
+                const uint32_t s = find_seed(L.off, cnt, h);
+                ss[u] = s;
+                tt[u] = h - L.off[s];
+                v[u] = sa_locate(ix, (L.srec[s] & ((1ull << 40) - 1ull)) + tt[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < VOTE_U; ++u) {
+            const uint32_t h = hb + (uint32_t) u * 64 + lane;
+            if (h < total) {
+                const uint32_t q = L.sq[ss[u]];
+                const uint64_t key = v[u] - (uint64_t) (iter + q * P);              // alnmain.c:363-365 (u64 wrap kept)
+                const uint32_t hash = bucket_hash(key >> 4);
+                if (!vote_count_if_present(t, key, (q << tbits) | tt[u], hash)) {
+                    const uint32_t c = (hash >> 5) & (2 * FAST_SK_WORDS - 1);
+                    atomicAdd(&L.sketch[c >> 1], 1u << (16 * (c & 1)));            // < 2^16 hits per bucket: 16 per seed at most
+                }
+            }
+        }
+    }
+}
+
+#define FAST_CH 16                           // items per ticket of a wavefront
+template <int VOTE_U>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
+void vote_fast_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec, const uint32_t *__restrict__ recq,
+                      const uint32_t *__restrict__ gcnt, const uint32_t *__restrict__ ghits,
+                      const uint8_t *__restrict__ decided, uint64_t n, int seed_len, int phase_lo, int phase_hi,
+                      uint32_t cap_q, uint32_t tbits, uint32_t load, unsigned long long *ticket,
+                      LrmPhaseRes *__restrict__ phase_res, uint64_t *__restrict__ redo, unsigned long long *redo_n) {
+    __shared__ FastLds lds[4];
+    const uint32_t lane = threadIdx.x & 63u;
+    FastLds &L = lds[threadIdx.x >> 6];
+    const uint32_t P = (uint32_t) seed_len + 1;
+    const uint32_t np = (uint32_t) (phase_hi - phase_lo + 1);
+    const uint64_t n_items = n * (uint64_t) np;
+    constexpr int NU = (T1_LIMIT + 63) / 64;
+    for (;;) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(ticket, (unsigned long long) FAST_CH);
+        base = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (base >> 32)) << 32) |
+               (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) base);
+        if (base >= n_items) break;
+        uint64_t read = base / np;
+        uint32_t pi = (uint32_t) (base - read * np);
+        for (uint32_t it = 0; it < FAST_CH && base + it < n_items; ++it, ++pi) {
+            if (pi == np) { pi = 0; ++read; }
+            const uint64_t item = base + it;
+            const uint32_t iter = (uint32_t) phase_lo + pi;
+            const uint64_t id = read * (uint64_t) P + iter;
+            if (decided && decided[read]) continue;
+            const uint32_t H = ghits[id], cnt = gcnt[id];
+            if (H == 0) {
+                if (lane == 0) { LrmPhaseRes z = {0, 0, 0, 0, 0, 0}; phase_res[id] = z; }
+                continue;
+            }
+            if (cnt > (uint32_t) T1_LIMIT) {                                   // more survivors than the wavefront table is sized for
+                if (lane == 0) redo[atomicAdd(redo_n, 1ull)] = item;
+                continue;
+            }
+            VoteTable t = {L.key, L.cf, 0};
+            {
+                const uint32_t eff = cnt * 100u / load + 64;
+                t.slots = eff < (uint32_t) T1_SLOTS ? eff : (uint32_t) T1_SLOTS;
+            }
+            const uint64_t *irec = rec + id * cap_q;
+            const uint32_t *iq = recq + id * cap_q;
+            uint64_t e[NU], sv[NU];
+            uint32_t qq[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {                                   // survivor loads first, clears behind them
+                const uint32_t s = (uint32_t) u * 64 + lane;
+                e[u] = s < cnt ? irec[s] : 0ull;
+                qq[u] = s < cnt ? iq[s] : 0u;
+            }
+            for (uint32_t s = lane; s < t.slots; s += 64) { t.key[s] = EMPTY_KEY; t.cf[s] = 0; }
+#pragma unroll
+            for (uint32_t s = 0; s < FAST_SK_WORDS / 64; ++s) L.sketch[s * 64 + lane] = 0;
+            unsigned long long any_big = 0;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const uint32_t rr = (uint32_t) (e[u] >> 40);
+                sv[u] = rr == 1 ? sa_locate(ix, e[u] & ((1ull << 40) - 1ull)) : 0ull;       // unique seeds: gather at once
+                any_big |= __ballot(rr > 1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // A: the unique seeds' hits make the table
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+                if ((uint32_t) (e[u] >> 40) == 1) vote_admit(t, sv[u] - (uint64_t) (iter + qq[u] * P), qq[u] << tbits, 1u, 0u);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // B: the repeat seeds' hits, 64 survivors at a time
+            if (any_big) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const uint32_t rr = (uint32_t) (e[u] >> 40);
+                    const bool big = rr > 1;
+                    const unsigned long long bm = __ballot(big);
+                    if (bm == 0) continue;
+                    const uint32_t incl = wave_incl_scan(big ? rr : 0u);
+                    if (big) {
+                        const uint32_t idx = mask_rank(bm);
+                        L.off[idx] = incl - rr; L.srec[idx] = e[u]; L.sq[idx] = qq[u];
+                    }
+                    const uint32_t nb = (uint32_t) __popcll(bm);
+                    const uint32_t run = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+                    if (lane == 0) L.off[nb] = run;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    fast_hits<VOTE_U>(ix, t, L, nb, run, iter, P, tbits, lane);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            // C
+            const Top2 w = table_top2<64>(t, lane);
+            uint32_t m = 0;
+#pragma unroll
+            for (uint32_t s = 0; s < FAST_SK_WORDS / 64; ++s) {
+                const uint32_t x = L.sketch[s * 64 + lane];
+                const uint32_t a = x & 0xffffu, b = x >> 16;
+                m = a > m ? a : m;
+                m = b > m ? b : m;
+            }
+            const uint32_t M = (uint32_t) wave_max_u64((uint64_t) m);
+            const bool settled = any_big == 0 || M < (uint32_t) (w.k2 >> 32);
+            if (lane == 0) {
+                if (settled) {
+                    PhaseTop p = {};
+                    if (w.k1) { p.val1 = (uint32_t) (w.k1 >> 32); p.key1 = t.key[w.s1]; p.bucket1 = p.key1 >> 4; }
+                    if (w.k2) { p.val2 = (uint32_t) (w.k2 >> 32); p.key2 = t.key[w.s2]; p.bucket2 = p.key2 >> 4; }
+                    write_phase(&phase_res[id], p);
+                } else {
+                    redo[atomicAdd(redo_n, 1ull)] = item;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 #ifndef LRM_VOTE_WAVES_PER_EU
 #define LRM_VOTE_WAVES_PER_EU 6     // 79 VGPRs and 23.7 KB of LDS per workgroup: six workgroups per CU
 #endif
@@ -908,7 +1107,8 @@ void vote_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
                                                    uint32_t slots3, uint32_t limit3, uint32_t vg, uint32_t limit1, uint32_t load,
                                                    unsigned long long *ticket, uint64_t *__restrict__ kc_key_all,
                                                    uint32_t *__restrict__ kc_ord_all, uint32_t kc_cap,
-                                                   LrmPhaseRes *__restrict__ phase_res, uint32_t *err_word) {
+                                                   LrmPhaseRes *__restrict__ phase_res, uint32_t *err_word,
+                                                   const uint64_t *__restrict__ list, const unsigned long long *__restrict__ list_n) {
     __shared__ VoteLds lds;
     __shared__ uint32_t g_H[VG_MAX], g_cnt[VG_MAX], g_ph[VG_MAX];
     __shared__ uint64_t g_id[VG_MAX];
@@ -919,7 +1119,8 @@ void vote_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
     const int lane = (int) (tid & 63);
     const uint32_t P = (uint32_t) seed_len + 1;
     const uint32_t np = (uint32_t) (phase_hi - phase_lo + 1);
-    const uint64_t n_items = n * (uint64_t) np;
+    // list mode: the items the fast kernel could not settle (vote_fast_kernel), by their item numbers
+    const uint64_t n_items = list ? (uint64_t) *list_n : n * (uint64_t) np;
     const uint64_t n_groups = (n_items + vg - 1) / vg;
     uint64_t *kc_key = kc_key_all + (uint64_t) blockIdx.x * kc_cap;      // this workgroup's slice of the key scratch
     uint32_t *kc_ord = kc_ord_all + (uint64_t) blockIdx.x * kc_cap;
@@ -931,10 +1132,11 @@ void vote_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
     const uint64_t grp = s_grp;
     if (grp >= n_groups) break;
     if (tid < vg) {
-        const uint64_t item = grp * vg + tid;
+        const uint64_t li = grp * vg + tid;
+        const uint64_t item = list && li < n_items ? list[li] : li;
         uint32_t H = 0, c = 0, ph = 0;
         uint64_t id = 0;
-        if (item < n_items) {
+        if (li < n_items) {
             const uint64_t read = item / np;
             ph = (uint32_t) phase_lo + (uint32_t) (item - read * np);        // the item's phase (kept: a 64-bit modulo per item and wavefront is ~150 instructions)
             id = read * (uint64_t) P + (uint64_t) ph;
@@ -1119,10 +1321,26 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
         if (vblocks > LRM_VOTE_GRID) vblocks = LRM_VOTE_GRID;          // resident workgroups; groups of items go by ticket
         lrm_time_begin(ws, LRM_K_VOTE, stream);
         auto vk = vote_u == 2 ? vote_kernel<2> : vote_u == 8 ? vote_kernel<8> : vote_kernel<4>;
-        hipLaunchKernelGGL(vk, dim3((uint32_t) vblocks), dim3(256), 0, stream, idx->view, ws->d_rec, ws->d_recq,
-                           ws->d_cnt, ws->d_hcount, dec, n, (int) seed_len, lo, hi, cap_q, tbits, t3_slots, t3_limit,
-                           vg, t1_limit, vote_load, &ws->d_counters->reserved[1 + round], ws->d_kc_key, ws->d_kc_ord,
-                           (uint32_t) LRM_VOTE_KC_CAP, ws->d_phase, ws->d_err);
+        if (mt.vote_fast) {
+            // fast kernel over all items, then the exact kernel over the items it could not settle (its list)
+            uint64_t fblocks = (items + 4 * FAST_CH - 1) / (4 * FAST_CH);
+            if (fblocks > LRM_VOTE_FAST_GRID) fblocks = LRM_VOTE_FAST_GRID;
+            auto fk = vote_u == 2 ? vote_fast_kernel<2> : vote_u == 8 ? vote_fast_kernel<8> : vote_fast_kernel<4>;
+            hipLaunchKernelGGL(fk, dim3((uint32_t) fblocks), dim3(256), 0, stream, idx->view, ws->d_rec, ws->d_recq, ws->d_cnt,
+                               ws->d_hcount, dec, n, (int) seed_len, lo, hi, cap_q, tbits, vote_load,
+                               &ws->d_counters->vote_fast_ticket[round], ws->d_phase, ws->d_redo, &ws->d_counters->vote_redo_n[round]);
+            hipLaunchKernelGGL(vk, dim3((uint32_t) vblocks), dim3(256), 0, stream, idx->view, ws->d_rec, ws->d_recq,
+                               ws->d_cnt, ws->d_hcount, dec, n, (int) seed_len, lo, hi, cap_q, tbits, t3_slots, t3_limit,
+                               vg, t1_limit, vote_load, &ws->d_counters->reserved[1 + round], ws->d_kc_key, ws->d_kc_ord,
+                               (uint32_t) LRM_VOTE_KC_CAP, ws->d_phase, ws->d_err, (const uint64_t *) ws->d_redo,
+                               (const unsigned long long *) &ws->d_counters->vote_redo_n[round]);
+        } else {
+            hipLaunchKernelGGL(vk, dim3((uint32_t) vblocks), dim3(256), 0, stream, idx->view, ws->d_rec, ws->d_recq,
+                               ws->d_cnt, ws->d_hcount, dec, n, (int) seed_len, lo, hi, cap_q, tbits, t3_slots, t3_limit,
+                               vg, t1_limit, vote_load, &ws->d_counters->reserved[1 + round], ws->d_kc_key, ws->d_kc_ord,
+                               (uint32_t) LRM_VOTE_KC_CAP, ws->d_phase, ws->d_err, (const uint64_t *) nullptr,
+                               (const unsigned long long *) nullptr);
+        }
         lrm_time_end(ws, stream);
         lrm_time_begin(ws, LRM_K_DECIDE, stream);
         hipLaunchKernelGGL(decide_kernel, dim3((uint32_t) ((n + 255) / 256)), dim3(256), 0, stream, ws->d_phase,

@@ -219,7 +219,7 @@ class DeviceMapper:
         return dict(vote_tier2_items=int(st.vote_tier2_items), vote_tier3_items=int(st.vote_tier3_items),
                     reads_decided_phase0=int(st.reads_decided_phase0), gact_tiles=int(st.gact_tiles),
                     seeds_evaluated=int(st.seeds_evaluated), seed_table_lookups=int(st.seed_table_lookups),
-                    seed_rank_requests=int(st.seed_rank_requests))
+                    seed_rank_requests=int(st.seed_rank_requests), vote_redo_items=int(st.vote_redo_items))
 
     def set_counting(self, enable=True):
         """The next seed calls run the counting build of the seed kernel (stats(): requests of the device layout)."""
