@@ -810,7 +810,7 @@ extern "C" void lrm_workspace_free(lrm_workspace *ws) {
     if (!ws) return;
     (void) hipSetDevice(ws->device);
     (void) hipFree(ws->d_reads2); (void) hipFree(ws->d_rec); (void) hipFree(ws->d_phase); (void) hipFree(ws->d_decided);
-    (void) hipFree(ws->d_hcount); (void) hipFree(ws->d_counters); (void) hipFree(ws->d_recq); (void) hipFree(ws->d_cnt); (void) hipFree(ws->d_kc_key); (void) hipFree(ws->d_kc_ord); (void) hipFree(ws->d_redo);
+    (void) hipFree(ws->d_hcount); (void) hipFree(ws->d_counters); (void) hipFree(ws->d_recq); (void) hipFree(ws->d_cnt); (void) hipFree(ws->d_kc_key); (void) hipFree(ws->d_kc_ord); (void) hipFree(ws->d_redo); (void) hipFree(ws->d_big);
     (void) hipFree(ws->d_qpl); (void) hipFree(ws->d_rflags);
     (void) hipFree(ws->d_ckpt); (void) hipFree(ws->d_codes); (void) hipFree(ws->d_ncodes);
     if (ws->h_err) (void) hipHostFree((void *) ws->h_err);
@@ -859,6 +859,7 @@ int lrm_workspace_create_parts(lrm_workspace **out, lrm_index *idx, uint64_t n_m
         {(void **) &ws->d_kc_key, (uint64_t) LRM_VOTE_GRID * LRM_VOTE_KC_CAP * 8, LRM_WS_SEED},
         {(void **) &ws->d_kc_ord, (uint64_t) LRM_VOTE_GRID * LRM_VOTE_KC_CAP * 4, LRM_WS_SEED},
         {(void **) &ws->d_redo, n_max * (uint64_t) ws->P * 8, LRM_WS_SEED},
+        {(void **) &ws->d_big, n_max * (uint64_t) ws->P * 8, LRM_WS_SEED},
         {(void **) &ws->d_phase, n_max * (uint64_t) ws->P * sizeof(LrmPhaseRes), LRM_WS_SEED},
         {(void **) &ws->d_decided, n_max, LRM_WS_SEED},
         {(void **) &ws->d_hcount, n_max * (uint64_t) ws->P * 4, LRM_WS_SEED},

@@ -145,6 +145,8 @@ struct LrmDevCounters {
     unsigned long long pad[2];
     unsigned long long vote_fast_ticket[2];   // per seeding round: ticket of vote_fast_kernel,
     unsigned long long vote_redo_n[2];        //   items it left to the exact kernel
+    unsigned long long vote_big_n[2];         //   items it left to its workgroup form, and that kernel's ticket
+    unsigned long long vote_big_ticket[2];
 };
 // Error word of a workspace: ONE dword of host-coherent pinned memory that kernels set with a plain store (bit 0:
 // vote table overflow in the multi-pass tier).  It is never cleared by a launch, so an error raised by any
@@ -192,7 +194,8 @@ struct lrm_workspace {
     uint32_t *d_cnt;         // survivors per (read, phase)
     uint64_t *d_kc_key;      // vote kernel: per-workgroup scratch of the keys of multi-pass items (LRM_VOTE_GRID x LRM_VOTE_KC_CAP)
     uint32_t *d_kc_ord;      //              ... and their order keys
-    uint64_t *d_redo;        // items the fast vote kernel left to the exact one (n_max * P)
+    uint64_t *d_redo;        // items the fast vote kernels left to the exact one (n_max * P)
+    uint64_t *d_big;         // items the wavefront form left to the workgroup form (n_max * P)
     LrmPhaseRes *d_phase;    // n_max * P
     uint8_t *d_decided;      // n_max
     uint32_t *d_hcount;      // SA hits (sum of rr) per (read, phase): routes an item to its vote-table tier

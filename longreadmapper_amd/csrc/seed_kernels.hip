@@ -911,6 +911,7 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
 // hit count, and a wavefront stages its repeat seeds 64 survivors at a time.  Items with more than T1_LIMIT survivors go
 // to the exact kernel as well.
 #define FAST_SK_WORDS 512                    // 1024 16-bit counters per wavefront
+#define FB_LIMIT 1536                        // survivors up to which the workgroup form takes an item (75 % of its 2048 slots)
 struct FastLds {
     uint64_t key[T1_SLOTS];
     uint64_t cf[T1_SLOTS];
@@ -939,33 +940,34 @@ __device__ __forceinline__ bool vote_count_if_present(const VoteTable &t, uint64
     return false;
 }
 
-template <int VOTE_U>
-__device__ __forceinline__ void fast_hits(const LrmIndexView &ix, const VoteTable &t, FastLds &L, uint32_t cnt, uint32_t total,
+template <int NT, int VOTE_U>
+__device__ __forceinline__ void fast_hits(const LrmIndexView &ix, const VoteTable &t, const uint32_t *off, const uint64_t *srec,
+                                          const uint32_t *sq, uint32_t *sketch, uint32_t sk_mask, uint32_t cnt, uint32_t total,
                                           uint32_t iter, uint32_t P, uint32_t tbits, uint32_t lane) {
-    for (uint32_t hb = 0; hb < total; hb += 64 * VOTE_U) {
+    for (uint32_t hb = 0; hb < total; hb += NT * VOTE_U) {
         uint64_t v[VOTE_U];
         uint32_t ss[VOTE_U], tt[VOTE_U];
 #pragma unroll
         for (int u = 0; u < VOTE_U; ++u) {
-            const uint32_t h = hb + (uint32_t) u * 64 + lane;
+            const uint32_t h = hb + (uint32_t) u * NT + lane;
             v[u] = 0; ss[u] = 0; tt[u] = 0;
             if (h < total) {
-                const uint32_t s = find_seed(L.off, cnt, h);
+                const uint32_t s = find_seed(off, cnt, h);
                 ss[u] = s;
-                tt[u] = h - L.off[s];
-                v[u] = sa_locate(ix, (L.srec[s] & ((1ull << 40) - 1ull)) + tt[u]);
+                tt[u] = h - off[s];
+                v[u] = sa_locate(ix, (srec[s] & ((1ull << 40) - 1ull)) + tt[u]);
             }
         }
 #pragma unroll
         for (int u = 0; u < VOTE_U; ++u) {
-            const uint32_t h = hb + (uint32_t) u * 64 + lane;
+            const uint32_t h = hb + (uint32_t) u * NT + lane;
             if (h < total) {
-                const uint32_t q = L.sq[ss[u]];
+                const uint32_t q = sq[ss[u]];
                 const uint64_t key = v[u] - (uint64_t) (iter + q * P);              // alnmain.c:363-365 (u64 wrap kept)
                 const uint32_t hash = bucket_hash(key >> 4);
                 if (!vote_count_if_present(t, key, (q << tbits) | tt[u], hash)) {
-                    const uint32_t c = (hash >> 5) & (2 * FAST_SK_WORDS - 1);
-                    atomicAdd(&L.sketch[c >> 1], 1u << (16 * (c & 1)));            // < 2^16 hits per bucket: 16 per seed at most
+                    const uint32_t c = (hash >> 5) & sk_mask;
+                    atomicAdd(&sketch[c >> 1], 1u << (16 * (c & 1)));              // < 2^16 hits per bucket: 16 per seed at most
                 }
             }
         }
@@ -979,7 +981,8 @@ void vote_fast_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec, const u
                       const uint32_t *__restrict__ gcnt, const uint32_t *__restrict__ ghits,
                       const uint8_t *__restrict__ decided, uint64_t n, int seed_len, int phase_lo, int phase_hi,
                       uint32_t cap_q, uint32_t tbits, uint32_t load, unsigned long long *ticket,
-                      LrmPhaseRes *__restrict__ phase_res, uint64_t *__restrict__ redo, unsigned long long *redo_n) {
+                      LrmPhaseRes *__restrict__ phase_res, uint64_t *__restrict__ redo, unsigned long long *redo_n,
+                      uint64_t *__restrict__ big, unsigned long long *big_n) {
     __shared__ FastLds lds[4];
     const uint32_t lane = threadIdx.x & 63u;
     FastLds &L = lds[threadIdx.x >> 6];
@@ -1006,8 +1009,11 @@ void vote_fast_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec, const u
                 if (lane == 0) { LrmPhaseRes z = {0, 0, 0, 0, 0, 0}; phase_res[id] = z; }
                 continue;
             }
-            if (cnt > (uint32_t) T1_LIMIT) {                                   // more survivors than the wavefront table is sized for
-                if (lane == 0) redo[atomicAdd(redo_n, 1ull)] = item;
+            if (cnt > (uint32_t) T1_LIMIT) {                                   // more survivors than the wavefront table is sized for:
+                if (lane == 0) {                                               // the workgroup form of this kernel, or the exact kernel
+                    if (cnt <= (uint32_t) FB_LIMIT) big[atomicAdd(big_n, 1ull)] = item;
+                    else redo[atomicAdd(redo_n, 1ull)] = item;
+                }
                 continue;
             }
             VoteTable t = {L.key, L.cf, 0};
@@ -1061,7 +1067,7 @@ void vote_fast_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec, const u
                     if (lane == 0) L.off[nb] = run;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    fast_hits<VOTE_U>(ix, t, L, nb, run, iter, P, tbits, lane);
+                    fast_hits<64, VOTE_U>(ix, t, L.off, L.srec, L.sq, L.sketch, 2 * FAST_SK_WORDS - 1, nb, run, iter, P, tbits, lane);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -1090,6 +1096,137 @@ void vote_fast_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec, const u
             }
             __builtin_amdgcn_wave_barrier();
         }
+    }
+}
+
+// The same for items with up to FB_LIMIT survivors (reads of 100 kbp: ~1200 per item), one WORKGROUP per item: a
+// 2048-slot table for the unique seeds' buckets, a 4096-counter sketch, repeat seeds staged 256 survivors at a time.
+// One pass whatever the hit count (the exact kernel takes ceil(hits / 768) passes over its 1024-slot table: five on
+// such reads).  Works through the list the wavefront kernel leaves (`big`).
+#define FB_SLOTS 2048
+#define FB_SK_WORDS 2048
+struct FastBlockLds {
+    uint64_t key[FB_SLOTS];
+    uint64_t cf[FB_SLOTS];
+    uint64_t srec[T3_CHUNK];
+    uint32_t off[T3_CHUNK + 4];
+    uint32_t sq[T3_CHUNK];
+    uint32_t sketch[FB_SK_WORDS];
+};
+template <int VOTE_U>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void vote_fast_block_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec, const uint32_t *__restrict__ recq,
+                            const uint32_t *__restrict__ gcnt, const uint32_t *__restrict__ ghits, int seed_len,
+                            int phase_lo, int phase_hi, uint32_t cap_q, uint32_t tbits, uint32_t load,
+                            unsigned long long *ticket, LrmPhaseRes *__restrict__ phase_res,
+                            const uint64_t *__restrict__ big, const unsigned long long *__restrict__ big_n,
+                            uint64_t *__restrict__ redo, unsigned long long *redo_n) {
+    __shared__ FastBlockLds L;
+    __shared__ uint32_t s_wsum[8], s_m[4];
+    __shared__ Top2 s_top[4];
+    __shared__ unsigned long long s_at;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t P = (uint32_t) seed_len + 1;
+    const uint32_t np = (uint32_t) (phase_hi - phase_lo + 1);
+    const uint64_t n_big = (uint64_t) *big_n;
+    for (;;) {
+        if (tid == 0) s_at = atomicAdd(ticket, 1ull);
+        __syncthreads();
+        const uint64_t at = s_at;
+        if (at >= n_big) break;
+        const uint64_t item = big[at];
+        const uint64_t read = item / np;
+        const uint32_t iter = (uint32_t) phase_lo + (uint32_t) (item - read * np);
+        const uint64_t id = read * (uint64_t) P + iter;
+        const uint32_t cnt = gcnt[id];
+        const uint64_t *irec = rec + id * cap_q;
+        const uint32_t *iq = recq + id * cap_q;
+        VoteTable t = {L.key, L.cf, 0};
+        {
+            const uint32_t eff = cnt * 100u / load + 64;
+            t.slots = eff < (uint32_t) FB_SLOTS ? eff : (uint32_t) FB_SLOTS;
+        }
+        for (uint32_t s = tid; s < t.slots; s += 256) { t.key[s] = EMPTY_KEY; t.cf[s] = 0; }
+        for (uint32_t s = tid; s < FB_SK_WORDS; s += 256) L.sketch[s] = 0;
+        __syncthreads();
+        // A: the unique seeds' hits make the table
+        bool ok = true;
+        uint32_t any_big = 0;
+        for (uint32_t c0 = 0; c0 < cnt; c0 += 256) {
+            const uint64_t e0 = c0 + tid < cnt ? irec[c0 + tid] : 0ull;
+            const uint32_t r0 = (uint32_t) (e0 >> 40);
+            any_big |= r0 > 1 ? 1u : 0u;
+            if (r0 == 1) {
+                const uint32_t q0 = iq[c0 + tid];
+                const uint64_t v0 = sa_locate(ix, e0 & ((1ull << 40) - 1ull));
+                ok &= vote_admit(t, v0 - (uint64_t) (iter + q0 * P), q0 << tbits, 1u, 0u);
+            }
+        }
+        const bool block_big = __syncthreads_or((int) any_big) != 0;
+        // B: the repeat seeds' hits, 256 survivors at a time
+        if (block_big) {
+            for (uint32_t c0 = 0; c0 < cnt; c0 += 256) {
+                const uint64_t e0 = c0 + tid < cnt ? irec[c0 + tid] : 0ull;
+                const uint32_t q0 = c0 + tid < cnt ? iq[c0 + tid] : 0u;
+                const uint32_t r0 = (uint32_t) (e0 >> 40);
+                const bool b0 = r0 > 1;
+                const unsigned long long bm = __ballot(b0);
+                const uint32_t incl_h = wave_incl_scan(b0 ? r0 : 0u);
+                if (lane == 63) { s_wsum[wave] = incl_h; s_wsum[4 + wave] = (uint32_t) __popcll(bm); }
+                __syncthreads();
+                uint32_t woff_h = 0, total = 0, woff_n = 0, nbig = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < 4; ++w) {
+                    const uint32_t x = s_wsum[w], y = s_wsum[4 + w];
+                    total += x; nbig += y;
+                    if (w < wave) { woff_h += x; woff_n += y; }
+                }
+                if (b0) {
+                    const uint32_t idx = woff_n + mask_rank(bm);
+                    L.off[idx] = woff_h + incl_h - r0; L.srec[idx] = e0; L.sq[idx] = q0;
+                }
+                if (tid == 0) L.off[nbig] = total;
+                __syncthreads();
+                if (nbig) fast_hits<256, VOTE_U>(ix, t, L.off, L.srec, L.sq, L.sketch, 2 * FB_SK_WORDS - 1, nbig, total, iter, P, tbits, tid);
+                __syncthreads();                                   // the staging is rewritten by the next chunk
+            }
+        }
+        // C
+        const Top2 w = table_top2<256>(t, tid);
+        uint32_t m = 0;
+        for (uint32_t s = tid; s < FB_SK_WORDS; s += 256) {
+            const uint32_t x = L.sketch[s];
+            const uint32_t a = x & 0xffffu, b = x >> 16;
+            m = a > m ? a : m;
+            m = b > m ? b : m;
+        }
+        m = (uint32_t) wave_max_u64((uint64_t) m);
+        if (lane == 0) { s_top[wave] = w; s_m[wave] = m; }
+        const bool all_ok = __syncthreads_and((int) ok) != 0;
+        if (tid == 0) {
+            uint64_t ck[2] = {0, 0};
+            uint32_t cslot[2] = {0, 0}, M = 0;
+            for (int x = 0; x < 4; ++x) {
+                const Top2 c = s_top[x];
+                const uint64_t ks[2] = {c.k1, c.k2};
+                const uint32_t ss[2] = {c.s1, c.s2};
+                for (int y = 0; y < 2; ++y) {
+                    if (ks[y] > ck[0]) { ck[1] = ck[0]; cslot[1] = cslot[0]; ck[0] = ks[y]; cslot[0] = ss[y]; }
+                    else if (ks[y] > ck[1]) { ck[1] = ks[y]; cslot[1] = ss[y]; }
+                }
+                M = s_m[x] > M ? s_m[x] : M;
+            }
+            const bool settled = all_ok && (!block_big || M < (uint32_t) (ck[1] >> 32));
+            if (settled) {
+                PhaseTop p = {};
+                if (ck[0]) { p.val1 = (uint32_t) (ck[0] >> 32); p.key1 = t.key[cslot[0]]; p.bucket1 = p.key1 >> 4; }
+                if (ck[1]) { p.val2 = (uint32_t) (ck[1] >> 32); p.key2 = t.key[cslot[1]]; p.bucket2 = p.key2 >> 4; }
+                write_phase(&phase_res[id], p);
+            } else {
+                redo[atomicAdd(redo_n, 1ull)] = item;
+            }
+        }
+        __syncthreads();                                           // s_at, the table and s_top are rewritten by the next item
     }
 }
 
@@ -1328,7 +1465,14 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
             auto fk = vote_u == 2 ? vote_fast_kernel<2> : vote_u == 8 ? vote_fast_kernel<8> : vote_fast_kernel<4>;
             hipLaunchKernelGGL(fk, dim3((uint32_t) fblocks), dim3(256), 0, stream, idx->view, ws->d_rec, ws->d_recq, ws->d_cnt,
                                ws->d_hcount, dec, n, (int) seed_len, lo, hi, cap_q, tbits, vote_load,
-                               &ws->d_counters->vote_fast_ticket[round], ws->d_phase, ws->d_redo, &ws->d_counters->vote_redo_n[round]);
+                               &ws->d_counters->vote_fast_ticket[round], ws->d_phase, ws->d_redo, &ws->d_counters->vote_redo_n[round],
+                               ws->d_big, &ws->d_counters->vote_big_n[round]);
+            auto fbk = vote_u == 2 ? vote_fast_block_kernel<2> : vote_u == 8 ? vote_fast_block_kernel<8> : vote_fast_block_kernel<4>;
+            uint64_t bblocks = items < 768 ? items : 768;                     // three workgroups per CU
+            hipLaunchKernelGGL(fbk, dim3((uint32_t) bblocks), dim3(256), 0, stream, idx->view, ws->d_rec, ws->d_recq, ws->d_cnt,
+                               ws->d_hcount, (int) seed_len, lo, hi, cap_q, tbits, vote_load, &ws->d_counters->vote_big_ticket[round],
+                               ws->d_phase, (const uint64_t *) ws->d_big, (const unsigned long long *) &ws->d_counters->vote_big_n[round],
+                               ws->d_redo, &ws->d_counters->vote_redo_n[round]);
             hipLaunchKernelGGL(vk, dim3((uint32_t) vblocks), dim3(256), 0, stream, idx->view, ws->d_rec, ws->d_recq,
                                ws->d_cnt, ws->d_hcount, dec, n, (int) seed_len, lo, hi, cap_q, tbits, t3_slots, t3_limit,
                                vg, t1_limit, vote_load, &ws->d_counters->reserved[1 + round], ws->d_kc_key, ws->d_kc_ord,
