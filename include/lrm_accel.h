@@ -129,7 +129,8 @@ typedef struct lrm_map_options {
     int32_t gact_impl;         /* extension kernel: 0 automatic, 1 one read per wavefront, 3 two reads per wavefront,
                                   4 bit-sliced lane per read whenever it applies */
     int32_t seed_rounds;       /* 0 automatic (phase 0 first unless the previous batch decided < 2 % there), 1, 2 */
-    int32_t reserved0;         /* (was direct_rows: device row writes into pinned caller memory; measured and removed) */
+    int32_t vote_exact_only;   /* 1: every (read, phase) item goes through the exact vote kernel (the fast kernel in front of it
+                                  is skipped); results are identical either way -- tests and A/B timing */
     uint32_t slice_reads;      /* host pipeline shape, 0 = automatic: reads per device pass, */
     uint32_t sub_batches;      /*   seed sub-batches per pass, */
     uint32_t group_subs;       /*   sub-batches per extension group */

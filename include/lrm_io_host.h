@@ -27,6 +27,10 @@ typedef struct lrm_read_batch {
     uint32_t *lens;
     char **names;
     char **quals;
+    /* storage behind names[] / quals[] when the batch came from the parallel parser (NULL: one allocation per entry),
+     * and whether seqs is the caller's buffer (lrm_reader_next_into); lrm_read_batch_free looks at them */
+    char *name_arena, *qual_arena;
+    int seqs_borrowed;
 } lrm_read_batch;
 
 typedef struct lrm_reader lrm_reader;
@@ -36,6 +40,10 @@ int lrm_reader_open(lrm_reader **out, const char *path);
 /* Loads up to batch_size records; returns the number loaded (0 at end of file), <0 on error
  * (-2: quality string of a different length, like kseq). */
 int64_t lrm_reader_next(lrm_reader *r, uint64_t batch_size, lrm_read_batch *out);
+/* The same with the sequences written into a buffer of the caller (e.g. pinned memory from lrm_host_alloc, so that the
+ * batch can be handed to lrm_map_batch_submit without a staging copy) when n * (max_len + 1) <= seq_cap; otherwise the
+ * library allocates as lrm_reader_next does.  out->seqs_borrowed tells which. */
+int64_t lrm_reader_next_into(lrm_reader *r, uint64_t batch_size, lrm_read_batch *out, void *seq_buf, uint64_t seq_cap);
 void lrm_read_batch_free(lrm_read_batch *b);
 void lrm_reader_close(lrm_reader *r);
 

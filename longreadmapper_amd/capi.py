@@ -66,7 +66,7 @@ class IndexOptions(C.Structure):       # lrm_index_options
 
 class MapOptions(C.Structure):         # lrm_map_options
     _fields_ = [("struct_size", C.c_uint32), ("dense_results", C.c_int32), ("gact_impl", C.c_int32),
-                ("seed_rounds", C.c_int32), ("reserved0", C.c_int32), ("slice_reads", C.c_uint32),
+                ("seed_rounds", C.c_int32), ("vote_exact_only", C.c_int32), ("slice_reads", C.c_uint32),
                 ("sub_batches", C.c_uint32), ("group_subs", C.c_uint32), ("bs_waves", C.c_uint32),
                 ("reserved", C.c_uint32 * 10)]
 
@@ -79,7 +79,8 @@ class Stats(C.Structure):
 
 class ReadBatch(C.Structure):          # lrm_io_host.h
     _fields_ = [("n", C.c_uint64), ("stride", C.c_uint64), ("max_len", C.c_uint32), ("seqs", C.c_void_p),
-                ("lens", u32p), ("names", C.POINTER(C.c_char_p)), ("quals", C.POINTER(C.c_char_p))]
+                ("lens", u32p), ("names", C.POINTER(C.c_char_p)), ("quals", C.POINTER(C.c_char_p)),
+                ("name_arena", C.c_void_p), ("qual_arena", C.c_void_p), ("seqs_borrowed", C.c_int)]
 
 
 class HostIndex(C.Structure):          # lrm_index_host.h
@@ -187,6 +188,7 @@ SYMBOLS = {
     # lrm_io_host.h
     "lrm_reader_open": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p]),
     "lrm_reader_next": (C.c_int64, [C.c_void_p, C.c_uint64, C.POINTER(ReadBatch)]),
+    "lrm_reader_next_into": (C.c_int64, [C.c_void_p, C.c_uint64, C.POINTER(ReadBatch), C.c_void_p, C.c_uint64]),
     "lrm_read_batch_free": (None, [C.POINTER(ReadBatch)]),
     "lrm_reader_close": (None, [C.c_void_p]),
     "lrm_parse_cigar": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),

@@ -393,3 +393,106 @@ def test_round_policy_does_not_change_results(dev_indexes, map_options, name):
     map_options(di)
     for _ in range(3):                     # the adaptive policy: the second and third call see the first one's history
         assert np.array_equal(mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"]), want)
+
+
+def _seed_both(hi, reads, lens, gpu, thres=300, **mopts):
+    oi = orc.OracleIndex.from_host_index(hi)
+    want, _ = oi.seed_batch(reads, lens, 20, thres)
+    di = index.DeviceIndex.upload(hi, gpu)
+    try:
+        di.set_map_options(**mopts)
+        got = mapper.seed_batch(di, reads, lens, 20, thres)
+    finally:
+        di.close()
+    return oi, want, got
+
+
+@pytest.mark.parametrize("exact_only", [0, 1])
+def test_vote_wave_tier_at_its_limit(gpu, exact_only):
+    """An item with exactly T1_LIMIT = 192 hits from exactly T1_LIMIT / 2 = 96 repeat seeds of two hits each: the
+    wavefront tier's staging arrays (96 entries, sized on "a repeat seed has at least two hits") are full to the last
+    slot.  96 distinct 20-mers sit twice each in the reference; the read strings them together 21 bases apart, so that
+    phase 0 sees them all and nothing else."""
+    rng = np.random.default_rng(11)
+    kmers = [bytes(rng.choice(list(b"ACGT"), size=20).astype(np.uint8)) for _ in range(96)]
+    parts = []
+    for rep in range(2):
+        for i, k in enumerate(kmers):
+            parts.append(bytes(synth.reference(80 + (i * 7 + rep * 13) % 40, seed=1000 + 2 * i + rep)))
+            parts.append(k)
+    parts.append(bytes(synth.reference(500, seed=5)))
+    ref = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    hi = index.HostIndex.build([ref], hlen=8)
+    read = b"".join(k + b"ACGT"[i % 4:i % 4 + 1] for i, k in enumerate(kmers)) + bytes(synth.reference(25, seed=77))
+    reads = np.zeros((3, len(read) + 1), dtype=np.uint8)
+    lens = np.array([len(read), len(read), 900], dtype=np.uint32)
+    reads[0, :len(read)] = np.frombuffer(read, dtype=np.uint8)
+    reads[1] = reads[0]
+    reads[2, :900] = ref[3000:3900]
+    oi, want, got = _seed_both(hi, reads, lens, gpu, vote_exact_only=exact_only)
+    tr = oi.seed_read(read, 20, 300, trace=True)
+    ph0 = [(j, rr) for j, rr, _, _ in tr["seeds"] if j % 21 == 0]
+    assert sum(rr for _, rr in ph0) == 192 and sum(rr == 2 for _, rr in ph0) == 96      # H == T1_LIMIT, 96 repeat seeds
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("exact_only", [0, 1])
+def test_vote_key_scratch_at_its_capacity(gpu, exact_only):
+    """An item with exactly LRM_VOTE_KC_CAP = 16384 hits (64 seeds x 256 copies of a tandem block): the multi-pass tier
+    keeps the keys of such an item in its workgroup's slice of the key scratch, which is then full to the last entry
+    (22 passes over the 1024-slot table).  One more copy (257 x 64 hits) is past the capacity: the passes gather again."""
+    block = bytes(synth.reference(64 * 21, seed=3))
+    flank = lambda s: bytes(synth.reference(700, seed=s))
+    for copies in (256, 257):
+        ref = np.frombuffer(flank(1) + block * copies + flank(2), dtype=np.uint8)
+        hi = index.HostIndex.build([ref], hlen=8)
+        read = block + bytes(synth.reference(30, seed=9))
+        reads = np.zeros((2, len(read) + 1), dtype=np.uint8)
+        reads[0, :len(read)] = np.frombuffer(read, dtype=np.uint8)
+        reads[1, :700] = np.frombuffer(flank(1), dtype=np.uint8)
+        lens = np.array([len(read), 700], dtype=np.uint32)
+        oi, want, got = _seed_both(hi, reads, lens, gpu, vote_exact_only=exact_only)
+        tr = oi.seed_read(read, 20, 300, trace=True)
+        assert sum(rr for j, rr, _, _ in tr["seeds"] if j % 21 == 0) == 64 * copies
+        assert np.array_equal(got, want), copies
+
+
+def test_exact_vote_kernel_alone_equals_the_fast_path(dev_indexes, map_options):
+    """vote_exact_only = 1 skips the fast vote kernel: same best[] on every scenario (the fast kernel only ever settles
+    an item when its result is the exact one)."""
+    for name in workloads.SEED_SCENARIOS:
+        sc, di, oi = dev_indexes(name)
+        a = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+        map_options(di, vote_exact_only=1)
+        b = mapper.seed_batch(di, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+        map_options(di)
+        assert np.array_equal(a, b), name
+
+
+def test_oracle_and_product_each_build_their_own_index(gpu):
+    """Everywhere else the oracle ADOPTS the index the product's host builder made (OracleIndex.from_host_index), so a
+    wrong suffix array / BWT / lchash would be wrong on both sides.  Here the oracle builds its own index with its own
+    suffix sorter (orc_index_build) from the same multi-sequence text, the product builds its own, the two are compared
+    array by array, and the mapping results are compared on top."""
+    seqs = [synth.reference(700_000, seed=51, repeat_frac=0.05, rep_len=300, rep_copies=40, rep_div=0.05),
+            synth.reference(350_000, seed=52), synth.reference(60_000, seed=53)]
+    hi = index.HostIndex.build(seqs, names=["a", "b", "c"], hlen=10)
+    oi = orc.OracleIndex.build(seqs, o_ratio=32, hlen=10)
+    assert hi.length == oi.length >= 2_000_000
+    assert np.array_equal(hi.sa(), oi.sa()) and np.array_equal(hi.bwt(), oi.bwt())
+    assert np.array_equal(hi.c(), oi.c()) and np.array_equal(hi.o(), oi.o()) and np.array_equal(hi.lc(), oi.lc())
+    r = synth.reads(seqs, 96, 3000, synth.ONT, seed=7)
+    want_best, _ = oi.seed_batch(r["reads"], r["lens"], nthreads=8)
+    rc = r["reads"].copy()
+    want = oi.extend_batch(rc, r["lens"], want_best, nthreads=8)
+    di = index.DeviceIndex.upload(hi, gpu)
+    try:
+        rg = r["reads"].copy()
+        got = mapper.map_batch(di, rg, r["lens"])
+    finally:
+        di.close()
+    assert np.array_equal(got["best"], want_best) and np.array_equal(got["score"], want["score"]) and np.array_equal(rg, rc)
+    assert np.array_equal(got["n_ops"], want["n_ops"])
+    for i in range(len(want_best)):
+        k = int(want["n_ops"][i])
+        assert bytes(got["ops"][i, :k]) == bytes(want["ops"][i, :k]), i

@@ -60,6 +60,69 @@ def test_fastq_fasta_reader(tmp_path):
     lib.lrm_reader_close(rd)
 
 
+@pytest.mark.parametrize("batch", [1, 7, 1000, 100000])
+@pytest.mark.parametrize("trailing_newline", [True, False])
+def test_parallel_fastq_parser(tmp_path, batch, trailing_newline):
+    """4-line FASTQ goes through the parallel parser: the block is cut at arbitrary byte offsets, every piece
+    resynchronises to a record boundary (quality lines that start with '@' or '+' must not fool it), batches end at
+    any record.  Compared with a line-by-line parse; also gzip-compressed, and with the sequences written into a
+    caller's buffer (lrm_reader_next_into)."""
+    rng = np.random.default_rng(7)
+    recs = []
+    for i in range(3000):
+        ln = int(rng.choice([0, 1, 2, 50, 700, 3000, 9000]))
+        seq = bytes(rng.choice(list(b"ACGTN"), size=ln).astype(np.uint8))
+        qual = bytes(rng.choice(list(b"@+#I5!~"), size=ln).astype(np.uint8))
+        if ln and i % 3 == 0:
+            qual = b"@" + qual[1:]
+        if ln and i % 5 == 0:
+            qual = b"+" + qual[1:]
+        name = b"read_%d" % i + (b" a comment @+ with\ttabs" if i % 4 == 0 else b"")
+        recs.append((name, seq, qual))
+    txt = b"".join(b"@" + n + b"\n" + s + b"\n+" + (n if i % 7 == 0 else b"") + b"\n" + q + b"\n" for i, (n, s, q) in enumerate(recs))
+    if not trailing_newline:
+        txt = txt[:-1]
+    assert len(txt) > 6_000_000                                    # several pieces of >= 1 MiB
+    p = tmp_path / "big.fq"
+    p.write_bytes(txt)
+    want = [(n.split(b" ")[0].split(b"\t")[0].decode(), s, q) for n, s, q in recs]
+    got = _read_all(p, batch)
+    assert [(g[0], g[1], g[2]) for g in got] == want
+    if batch == 1000:
+        assert [g[3] for g in got[::1000]] == [1000, 1000, 1000]
+        gz = tmp_path / "big.fq.gz"
+        gz.write_bytes(gzip.compress(txt, 1))
+        assert [(g[0], g[1], g[2]) for g in _read_all(gz, batch)] == want
+        # sequences into a caller's buffer, too small for the second call
+        rd = C.c_void_p()
+        capi.check(lib.lrm_reader_open(C.byref(rd), str(p).encode()))
+        mine = np.full(1000 * 9001, 0x55, dtype=np.uint8)
+        b = capi.ReadBatch()
+        assert lib.lrm_reader_next_into(rd, 1000, C.byref(b), mine.ctypes.data, mine.nbytes) == 1000
+        assert b.seqs_borrowed == 1 and b.seqs == mine.ctypes.data
+        rows = mine[:1000 * b.stride].reshape(1000, b.stride)
+        for i in (0, 1, 17, 999):
+            assert bytes(rows[i, :b.lens[i]]) == recs[i][1] and not rows[i, b.lens[i]:].any()
+        lib.lrm_read_batch_free(C.byref(b))
+        assert lib.lrm_reader_next_into(rd, 1000, C.byref(b), mine.ctypes.data, 10) == 1000
+        assert b.seqs_borrowed == 0 and b.seqs != mine.ctypes.data
+        lib.lrm_read_batch_free(C.byref(b))
+        lib.lrm_reader_close(rd)
+
+
+def test_parser_falls_back_in_the_middle_of_a_file(tmp_path):
+    """4-line records first (parallel parser), then a multi-line record and CR LF lines: the general parser takes over
+    at that record; nothing is lost or duplicated."""
+    a = b"".join(b"@a%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(50))
+    b = b"@multi\nACGT\nACGT\n+\nIIII\nIIII\n@crlf\r\nGGCC\r\n+\r\n!!!!\r\n@z\nTT\n+\n##\n"
+    p = tmp_path / "mixed.fq"
+    p.write_bytes(a + b)
+    got = _read_all(p, 20)
+    assert [g[0] for g in got] == ["a%d" % i for i in range(50)] + ["multi", "crlf", "z"]
+    assert got[50][1] == b"ACGTACGT" and got[50][2] == b"IIIIIIII" and got[51][1] == b"GGCC" and got[51][2] == b"!!!!"
+    assert got[52][1] == b"TT"
+
+
 def test_parse_cigar_rle():
     rng = np.random.default_rng(2)
     for _ in range(200):

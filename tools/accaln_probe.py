@@ -28,7 +28,8 @@ with open(fq, "wb") as f:
     for i in range(n):
         f.write(b"@read%d\n" % i + r["reads"][i, :Lr].tobytes() + b"\n+\n" + q + b"\n")
 total, valid = C.c_uint64(), C.c_uint64()
-for rep in range(2):
+os.environ.setdefault("LRM_HOST_VERBOSE", "1")        # stage times of lrm_accaln on stderr
+for rep in range(3):
     t0 = time.perf_counter()
     capi.check(lib.lrm_accaln(fa.encode(), fq.encode(), sam.encode(), capi.Params(batch, 20, 300), capi.GactParams(0, 0, 0), 0,
                               1, C.byref(total), C.byref(valid)), "lrm_accaln")
