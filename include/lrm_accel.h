@@ -135,7 +135,10 @@ typedef struct lrm_map_options {
     uint32_t sub_batches;      /*   seed sub-batches per pass, */
     uint32_t group_subs;       /*   sub-batches per extension group */
     uint32_t bs_waves;         /* tests: cap on the resident wavefronts of the bit-sliced kernel (forces lane refills) */
-    uint32_t reserved[10];
+    uint32_t copy_threads;     /* memcpy team of the PAGEABLE paths (upload staging, result placement): 0 automatic (the host's CPU
+                                  share / replicas, at most 8 -- what 24 Gbp/s through pageable buffers needs), else 1..16; a caller
+                                  whose own threads need the cores (lrm_accaln's parser and formatter) says 1 or 2 */
+    uint32_t reserved[9];
 } lrm_map_options;
 void lrm_map_options_init(lrm_map_options *o);
 

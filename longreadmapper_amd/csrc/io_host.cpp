@@ -723,18 +723,25 @@ extern "C" int lrm_accaln(const char *genome, const char *reads_path, const char
         lrm_map_options mopt;
         lrm_map_options_init(&mopt);
         mopt.dense_results = 1;
+        mopt.copy_threads = 2;                      // the parser and the formatter need the cores
+        // Pinning the batch buffers (0.2 s per GB to pin and to release, and the device stalls while the runtime pins)
+        // pays from a few tens of Gbp on: reads files below 16 GiB run through pageable buffers.
+        bool want_pinned = false;
+        { struct stat st; if (stat(reads_path, &st) == 0 && (uint64_t) st.st_size >= (16ull << 30)) want_pinned = true; }
         // Pinning memory costs ~0.2 s per GB: a thread of its own sizes the sets' pinned buffers from the first batch
         // (+ 1/8) while the first batches already run through pageable memory (staged upload, staged dense download).
         std::mutex dims_m;
         std::condition_variable dims_cv;
         uint64_t dim_reads = 0, dim_store = 0;
-        bool dims_known = false, dims_stop = false;
+        bool dims_known = false, dims_stop = false, first_submitted = false;
         std::thread pinner([&]() {
             if (hipSetDevice(device) != hipSuccess) { (void) hipGetLastError(); }
             {
                 std::unique_lock<std::mutex> lk(dims_m);
-                dims_cv.wait(lk, [&] { return dims_known || dims_stop; });
-                if (!dims_known) return;
+                // (after the first submit: that call builds the handle's host context -- streams, staging, mirrors -- and
+                //  would queue behind the runtime's lock while gigabytes are being pinned here)
+                dims_cv.wait(lk, [&] { return (dims_known && first_submitted) || dims_stop; });
+                if (!dims_known || dims_stop || !want_pinned) return;
             }
             for (auto &sp : sets) {
                 { std::lock_guard<std::mutex> lk(dims_m); if (dims_stop) return; }
@@ -744,6 +751,7 @@ extern "C" int lrm_accaln(const char *genome, const char *reads_path, const char
                 if (!s->reads_pin || !s->store_pin) { lrm_host_free(s->reads_pin); lrm_host_free(s->store_pin); s->reads_pin = nullptr; s->store_pin = nullptr; return; }
                 s->reads_cap = dim_reads; s->store_cap = dim_store;
                 s->pin_ready.store(true, std::memory_order_release);
+                if (verbose) fprintf(stderr, "[lrm accaln] %.3f pinned a set (%.2f + %.2f GB)\n", now() - t_upload, dim_reads / 1e9, dim_store / 1e9);
             }
         });
         std::thread loader([&]() {                                            // alnmain.c:302
@@ -753,6 +761,7 @@ extern "C" int lrm_accaln(const char *genome, const char *reads_path, const char
                 const bool pinned = s->pin_ready.load(std::memory_order_acquire);
                 int64_t n = lrm_reader_next_into(rd, bs, &s->b, pinned ? s->reads_pin : nullptr, pinned ? s->reads_cap : 0);
                 t_load += now() - t0;
+                if (verbose) fprintf(stderr, "[lrm accaln] %.3f loaded %lld reads in %.3f s (%s)\n", now() - t_upload, (long long) n, now() - t0, pinned ? "pinned" : "pageable");
                 if (n < 0) { err.set(-1); break; }
                 if (n == 0) { BatchSet *q = s; free_sets.push(std::move(q)); break; }
                 if (!dims_known) {
@@ -766,16 +775,38 @@ extern "C" int lrm_accaln(const char *genome, const char *reads_path, const char
             }
             loaded.close();
         });
-        std::thread writer([&]() {                                            // PART 3, alnmain.c:458-527
+        // PART 3, alnmain.c:458-527, in two stages: the formatter turns a mapped batch into SAM text (one part per thread)
+        // and gives the set back; the flusher writes the parts of the previous batch with parallel pwrites meanwhile.
+        struct TextBatch { std::vector<std::string> parts; };
+        StageQueue<std::unique_ptr<TextBatch>> texts(2), free_texts(3);
+        for (int k = 0; k < 3; ++k) { std::unique_ptr<TextBatch> tb(new TextBatch); free_texts.push(std::move(tb)); }
+        std::thread formatter([&]() {
             BatchSet *s = nullptr;
-            std::vector<std::string> parts;
             while (mapped.pop(s)) {
-                if (!err.get()) {
+                std::unique_ptr<TextBatch> tb;
+                if (!err.get() && free_texts.pop(tb)) {
                     const uint64_t n = s->b.n;
                     const double t0 = now();
                     sam_format_parts(&s->b, hi.mta, hi.mta_len, s->cig.data(), s->score.data(), s->meta.data(), s->meta_r.data(), n,
-                                     io_threads, parts);
+                                     io_threads, tb->parts);
+                    t_fmt += now() - t0;
+                    if (verbose) fprintf(stderr, "[lrm accaln] %.3f formatted %llu reads in %.3f s\n", now() - t_upload, (unsigned long long) n, now() - t0);
+                    total += n;
+                    for (uint64_t i = 0; i < n; ++i) valid += (s->score[i] >= 0 && s->meta_r[i] != 0) ? 1 : 0;   // alnmain.c:464-469,489-491
+                    if (!texts.push(std::move(tb))) err.set(-1);
+                }
+                lrm_read_batch_free(&s->b);
+                BatchSet *q = s;
+                free_sets.push(std::move(q));
+            }
+            texts.close();
+        });
+        std::thread flusher([&]() {
+            std::unique_ptr<TextBatch> tb;
+            while (texts.pop(tb)) {
+                if (!err.get()) {
                     const double t1 = now();
+                    std::vector<std::string> &parts = tb->parts;
                     std::vector<uint64_t> at(parts.size() + 1, out_off);
                     for (size_t k = 0; k < parts.size(); ++k) at[k + 1] = at[k] + parts[k].size();
                     bool ok = true;
@@ -790,14 +821,12 @@ extern "C" int lrm_accaln(const char *genome, const char *reads_path, const char
                     }
                     out_off = at[parts.size()];
                     if (!ok) { lrm_set_error("cannot write: %s", sam_path); err.set(-1); }
-                    t_fmt += t1 - t0; t_write += now() - t1;
-                    total += n;
-                    for (uint64_t i = 0; i < n; ++i) valid += (s->score[i] >= 0 && s->meta_r[i] != 0) ? 1 : 0;   // alnmain.c:464-469,489-491
+                    t_write += now() - t1;
+                    if (verbose) fprintf(stderr, "[lrm accaln] %.3f wrote %.2f GB in %.3f s\n", now() - t_upload, (at[parts.size()] - at[0]) / 1e9, now() - t1);
                 }
-                lrm_read_batch_free(&s->b);
-                BatchSet *q = s;
-                free_sets.push(std::move(q));
+                if (!free_texts.push(std::move(tb))) break;
             }
+            free_texts.close();
         });
         std::deque<BatchSet *> inflight;
         auto finish_oldest = [&]() {
@@ -806,6 +835,7 @@ extern "C" int lrm_accaln(const char *genome, const char *reads_path, const char
             const double t0 = now();
             const int mrc = lrm_map_batch_wait(s->ticket);
             t_map += now() - t0;
+            if (verbose) fprintf(stderr, "[lrm accaln] %.3f waited %.3f s for a batch of %llu\n", now() - t_upload, now() - t0, (unsigned long long) s->b.n);
             s->ticket = nullptr;
             if (mrc) { err.set(-1); lrm_read_batch_free(&s->b); BatchSet *q = s; free_sets.push(std::move(q)); return; }
             if (!mapped.push(std::move(s))) { /* writer gone: error path */ }
@@ -832,6 +862,8 @@ extern "C" int lrm_accaln(const char *genome, const char *reads_path, const char
             const int src = lrm_map_batch_submit(gpu, s->b.seqs, s->b.stride, s->b.lens, (uint64_t) n, p, gp, s->best.data(), s->cig.data(),
                                                  s->store, s->sstride, s->score.data(), s->meta.data(), s->meta_r.data(), &mopt, &s->ticket);
             t_map += now() - t0;
+            if (verbose) fprintf(stderr, "[lrm accaln] %.3f submitted %zu reads (%s store) in %.3f s\n", now() - t_upload, n, s->store == s->store_pin ? "pinned" : "pageable", now() - t0);
+            if (!first_submitted) { { std::lock_guard<std::mutex> lk(dims_m); first_submitted = true; } dims_cv.notify_all(); }
             if (src) { err.set(-1); lrm_read_batch_free(&s->b); BatchSet *q = s; free_sets.push(std::move(q)); continue; }
             inflight.push_back(s);
             if (inflight.size() >= 3) finish_oldest();                        // two on the device, one queued behind them
@@ -840,14 +872,18 @@ extern "C" int lrm_accaln(const char *genome, const char *reads_path, const char
         mapped.close();
         free_sets.close();
         loader.join();
-        writer.join();
+        formatter.join();
+        flusher.join();
         { std::lock_guard<std::mutex> lk(dims_m); dims_stop = true; }
         dims_cv.notify_all();
         pinner.join();
         rc = err.get();
         if (rc) lrm_set_error("%s", err.msg.c_str());
+        const double t_done = now();
         if (gpu) { lrm_index_free(gpu); gpu = nullptr; }                      // before the pinned buffers of the sets go
         sets.clear();
+        if (verbose) fprintf(stderr, "[lrm accaln] last batch written %.2f s after the upload; freeing the device image and the pinned sets %.2f s\n",
+                             t_done - t_upload, now() - t_done);
     }
     if (rd) lrm_reader_close(rd);
     if (out_fd >= 0) close(out_fd);

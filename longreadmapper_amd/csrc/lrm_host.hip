@@ -233,14 +233,14 @@ bool is_pinned(const void *p, void **dev_alias = nullptr) {
 
 // host -> device on the upload stream; returns when the last byte has been handed to the DMA engine (not when
 // it has landed: later work is ordered behind the upload stream)
-int h2d(LrmHostCtx &c, void *d_dst, const void *h_src, uint64_t bytes, bool pinned) {
+int h2d(LrmHostCtx &c, void *d_dst, const void *h_src, uint64_t bytes, bool pinned, int threads) {
     if (bytes == 0) return 0;
     if (pinned) { HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c.up)); return 0; }
     for (uint64_t o = 0; o < bytes; o += STAGE_CHUNK, ++c.up_seq) {
         const int b = (int) (c.up_seq & 1);
         const uint64_t l = bytes - o < STAGE_CHUNK ? bytes - o : STAGE_CHUNK;
         if (c.pin_up_used[b] && wait_event(c.ev_pin_up[b])) return -1;         // the chunk's previous DMA has drained
-        par_memcpy(c.pin_up[b], (const char *) h_src + o, l, c.copy_threads);
+        par_memcpy(c.pin_up[b], (const char *) h_src + o, l, threads);
         HIPCHK(hipMemcpyAsync((char *) d_dst + o, c.pin_up[b], l, hipMemcpyHostToDevice, c.up));
         HIPCHK(hipEventRecord(c.ev_pin_up[b], c.up));
         c.pin_up_used[b] = true;
@@ -472,7 +472,7 @@ int plan_and_issue(LrmHostCtx &c, SliceJob &sj) {
         const uint64_t m = subs[k].m, off = subs[k].off;
         const double t_i0 = sj.clk.ms();
         char *dr = (char *) d.reads.p + off * j.stride;
-        if (h2d(c, dr, j.reads + off * j.stride, m * j.stride, pin_reads)) return -1;
+        if (h2d(c, dr, j.reads + off * j.stride, m * j.stride, pin_reads, mt.copy_threads ? (int) mt.copy_threads : c.copy_threads)) return -1;
         HIPCHK(hipMemcpyAsync((uint32_t *) d.lens.p + off, j.lens + off, m * 4, hipMemcpyHostToDevice, c.up));
         if (!(j.mode & DO_SEED)) HIPCHK(hipMemcpyAsync((lrm_entry *) d.best.p + off, j.best_in + off, m * sizeof(lrm_entry), hipMemcpyHostToDevice, c.up));
         HIPCHK(hipEventRecord(S.ev_up[k], c.up));
@@ -545,6 +545,7 @@ int collect(LrmHostCtx &c, SliceJob &sj, size_t g) {
     uint8_t *h_store = j.store_mem + o * j.store_stride;
     const bool pin_store = is_pinned(h_store);
     const bool dense = sj.mt.dense != 0;
+    const int copy_threads = sj.mt.copy_threads ? (int) sj.mt.copy_threads : c.copy_threads;
     uint64_t total_ops = 0, total = 0;
     for (uint64_t i = 0; i < m; ++i) {
         const uint64_t cap = j.store_stride;
@@ -595,11 +596,11 @@ int collect(LrmHostCtx &c, SliceJob &sj, size_t g) {
             std::vector<uint64_t> roff(m);
             for (uint64_t i = 0; i < m; ++i) roff[i] = h_off[m + i] - total_ops;
             if (d2h_ring(c, dn + total_ops, total - total_ops, roff.data(), h_len + m, dst.data() + m, m, nullptr, 1, ops_dma)) return -1;
-            if (total_ops && !pin_store && d2h_ring(c, dn, total_ops, nullptr, nullptr, nullptr, 0, h_store, c.copy_threads, []() { return 0; })) return -1;
+            if (total_ops && !pin_store && d2h_ring(c, dn, total_ops, nullptr, nullptr, nullptr, 0, h_store, copy_threads, []() { return 0; })) return -1;
         } else {
             // row layout (alnmain.c:322-325): every used CIGAR row and every reverse-complemented read is placed by the
             // host's memcpy team
-            if (d2h_ring(c, dn, total, h_off, h_len, dst.data(), 2 * m, nullptr, c.copy_threads, []() { return 0; })) return -1;
+            if (d2h_ring(c, dn, total, h_off, h_len, dst.data(), 2 * m, nullptr, copy_threads, []() { return 0; })) return -1;
         }
         HIPCHK(hipEventRecord(S.ev_dense[b], c.down));
         S.dense_used[b] = true;

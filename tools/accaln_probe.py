@@ -30,6 +30,8 @@ with open(fq, "wb") as f:
 total, valid = C.c_uint64(), C.c_uint64()
 os.environ.setdefault("LRM_HOST_VERBOSE", "1")        # stage times of lrm_accaln on stderr
 for rep in range(3):
+    if os.path.exists(sam):
+        os.remove(sam)                      # (truncating the previous run's gigabytes would be timed otherwise)
     t0 = time.perf_counter()
     capi.check(lib.lrm_accaln(fa.encode(), fq.encode(), sam.encode(), capi.Params(batch, 20, 300), capi.GactParams(0, 0, 0), 0,
                               1, C.byref(total), C.byref(valid)), "lrm_accaln")
