@@ -10,7 +10,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles", tag)
@@ -23,6 +23,8 @@ LAUNCHES_PER_STEP = {"pack2bit_kernel": 1, "seed_search_kernel": 2, "vote_kernel
 
 def short(name):
     n = name.replace("void ", "").split("(")[0].split("<")[0]
+    if n in ("vote_fast_kernel", "vote_fast_block_kernel"):      # the vote stage is three launches per seeding round: fast
+        n = "vote_kernel"                                       # (wavefront form), fast (workgroup form), exact (the list)
     return n
 
 
@@ -36,6 +38,7 @@ for _k, _v in (_b.get("isolated") or {}).get("kernels", {}).items():       # lau
     if _k in LAUNCHES_PER_STEP and _b.get("steps"):
         LAUNCHES_PER_STEP[_k] = max(1, round(_v["launches"] / _b["steps"]))
 
+LAUNCHES_PER_STEP["vote_kernel"] *= 3
 per_kernel = collections.defaultdict(dict)
 for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
     rows = list(csv.DictReader(open(f)))
@@ -127,8 +130,18 @@ with open(os.path.join(dst, "README.md"), "w") as f:
                 % (bu["value"], bu["ms_per_step"]))
     if bench.get("pcie_inclusive"):
         pi = bench["pcie_inclusive"]
-        f.write("PCIe-inclusive (SURVEY 8(d): `lrm_map_batch` on caller buffers, H2D of reads + D2H of results timed): pinned "
-                "**%.2f Gbp/s**, pageable %.2f Gbp/s.\n\n" % (pi["pinned"]["value"], pi["pageable"]["value"]))
+        f.write("PCIe-inclusive (SURVEY 8(d): caller buffers, H2D of reads + D2H of results timed):\n\n| leg | Gbp/s | ms per batch | host CPU s per Gbp |\n|---|---|---|---|\n")
+        for k, v in pi.items():
+            if isinstance(v, dict) and "ms_per_batch" in v:
+                f.write("| %s | %.2f | %.1f | %.3f |\n" % (k, v["value"], v["ms_per_batch"], v["host_cpu_s_per_Gbp"]))
+        f.write("\n")
+    g = bench.get("grch38")
+    if g and g.get("value"):
+        f.write("GRCh38-sized leg of the same command (fresh child process, %.0f s): **%.2f Gbp/s** HBM-resident (%.1f ms per step), "
+                "%.2f Gbp/s PCIe-inclusive, serialized replay %.1f ms per step (seed_search %.2f, vote %.2f, gact_bs %.2f), x%.0f the CPU oracle "
+                "on %d threads.\n\n" % (g["child_wall_s"], g["value"], g["ms_per_step"], g["value_pcie_inclusive"], g["isolated"]["ms_per_step"],
+                                        g["isolated"]["kernel_avg_ms"]["seed_search_kernel"], g["isolated"]["kernel_avg_ms"]["vote_kernel"],
+                                        g["isolated"]["kernel_avg_ms"]["gact_bs_kernel"], g["speedup_vs_cpu"], g["cpu_baseline"]["cores"]))
     f.write("## HIP-event timing inside bench.py, default command (durations include the overlap with other steps' kernels)\n\n")
     f.write(event_table(bench))
     if bench.get("isolated"):
