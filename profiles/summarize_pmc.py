@@ -60,7 +60,8 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.
             for c, v in per[(k, d)].items():
                 agg[c] += v
         per_kernel[k].update(agg)
-        per_kernel[k]["launches_per_step"] = LAUNCHES_PER_STEP[k]
+        # (bench.py brackets the three vote launches of a seeding round with ONE pair of HIP events: one "launch" there)
+        per_kernel[k]["launches_per_step"] = LAUNCHES_PER_STEP[k] // 3 if k == "vote_kernel" else LAUNCHES_PER_STEP[k]
 
 bench = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
 summary = {"workload": bench["config"], "note": "per timed step (1 Gbp); FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them",
