@@ -300,20 +300,22 @@ def main():
                                    "reverse-complemented reads) inside the timed region; the caller's own batch load (copying "
                                    "the reads into the buffer) is untimed")
 
-        def leg(kind, dense, inflight):
+        def leg(kind, layout, inflight):
+            dense = layout != "rows"
             if kind == "pinned":
                 bufs = [(mapper.pinned_empty((n, stride)), mapper.pinned_empty((n, sstride))) for _ in range(NB if inflight > 1 else 1)]
             else:
                 bufs = [(np.empty((n, stride), dtype=np.uint8), np.empty((n, sstride), dtype=np.uint8)) for _ in range(NB if inflight > 1 else 1)]
-            opts = dict(dense_results=1) if dense else {}
+            opts = dict(cigar_text=1) if layout == "text" else dict(dense_results=1) if dense else {}
             for hr, hs in bufs:
                 hs[:] = 0
                 hr[:] = r["reads"]
             # warm-up: device mirrors, workspaces, both slots
             w = [mapper.map_batch_submit(di, hr, r["lens"], args.seed_len, args.thres, gact, store=hs, options=opts) for hr, hs in bufs]
             res = [x.wait() for x in w][0]
-            res = dict(best=res["best"].copy(), score=res["score"].copy(), n_ops=res["n_ops"].copy(),
-                       ops0=[mapper.ops_of(res, i) for i in range(min(n, 64))], reads0=bufs[0][0][:64].copy())
+            res = dict(best=res["best"].copy(), score=res["score"].copy(), n_ops=res["n_ops"].copy(), layout=layout,
+                       ops0=[mapper.text_of(res, i) if layout == "text" else mapper.ops_of(res, i) for i in range(min(n, 64))],
+                       reads0=bufs[0][0][:64].copy())
             for hr, hs in bufs:
                 hr[:] = r["reads"]                                                             # untimed: the caller's batch load
             barrier()
@@ -346,7 +348,7 @@ def main():
                 wall, cpu = time.perf_counter() - t1, process_cpu_s() - c0
             wall = max_over_ranks(wall)
             out = dict(value=bases * world * ps / wall / 1e9, unit="Gbp/s", ms_per_batch=wall / ps * 1e3,
-                       host_cpu_s_per_Gbp=cpu / (bases * ps / 1e9), buffers=kind, result_layout="dense" if dense else "rows",
+                       host_cpu_s_per_Gbp=cpu / (bases * ps / 1e9), buffers=kind, result_layout=layout,
                        batches_submitted_ahead=inflight)
             if kind == "pinned":
                 for hr, hs in bufs:
@@ -355,12 +357,12 @@ def main():
             del bufs
             return out, res
 
-        legs = [("in_flight_dense_pinned", "pinned", True, 3), ("one_call_dense_pinned", "pinned", True, 1),
-                ("one_call_rows_pinned", "pinned", False, 1), ("one_call_rows_pageable", "pageable", False, 1),
-                ("in_flight_rows_pageable", "pageable", False, 3)]
+        legs = [("in_flight_dense_pinned", "pinned", "dense", 3), ("in_flight_text_pinned", "pinned", "text", 3),
+                ("one_call_dense_pinned", "pinned", "dense", 1), ("one_call_rows_pinned", "pinned", "rows", 1),
+                ("one_call_rows_pageable", "pageable", "rows", 1), ("in_flight_rows_pageable", "pageable", "rows", 3)]
         pcie_res = {}
-        for name, kind, dense, infl in legs:
-            pcie[name], pcie_res[name] = leg(kind, dense, infl)
+        for name, kind, layout, infl in legs:
+            pcie[name], pcie_res[name] = leg(kind, layout, infl)
             if rank == 0:
                 log("pcie leg %-26s %6.2f Gbp/s  %6.1f ms per batch  host CPU %.3f s per Gbp"
                     % (name, pcie[name]["value"], pcie[name]["ms_per_batch"], pcie[name]["host_cpu_s_per_Gbp"]))
@@ -369,6 +371,9 @@ def main():
         pcie["value_leg"] = ("in_flight_dense_pinned: lrm_map_batch_submit / lrm_map_batch_wait, two batches on the device and one "
                              "queued, dense result layout DMA'd into pinned caller memory")
         pcie["host_cpu_s_per_Gbp"] = pcie["in_flight_dense_pinned"]["host_cpu_s_per_Gbp"]
+        pcie["text_layout_note"] = ("in_flight_text_pinned hands back the run-length CIGAR TEXT parse_cigar would print from the op bytes "
+                                    "(lrm_map_options.cigar_text: the run-length pass runs on the device, ~0.45 instead of 1.1 bytes per read "
+                                    "base come down) -- another result format, so it is reported next to the headline, not as it")
         pcie["bytes_per_batch"] = dict(h2d=int(n * stride + 4 * n), d2h_reads="reverse-strand rows only (~half of n x read_len)",
                                        d2h_ops="used op bytes (16-byte aligned per read)", d2h_small=int(n * 60))
         pcie["inversion_r2"] = ("BENCH_r02 had pinned (15.97) below pageable (16.90): the result scatter was on the call's critical "
@@ -441,7 +446,12 @@ def main():
             assert np.array_equal(pr["best"][:sample_n], best) and np.array_equal(pr["score"][:sample_n], ext["score"])
             k0 = min(64, sample_n)
             for i in range(k0):
-                assert pr["ops0"][i] == bytes(ext["ops"][i, :int(ext["n_ops"][i])]), "host boundary (%s): op bytes differ from the oracle" % name
+                want_ops = bytes(ext["ops"][i, :int(ext["n_ops"][i])])
+                if pr["layout"] == "text":
+                    none = not want_ops or ext["meta_r"][i] == 0 or ext["score"][i] == -1
+                    assert pr["ops0"][i].decode() == ("*" if none else orc.parse_cigar(want_ops)), "host boundary (%s): CIGAR text differs from the oracle's" % name
+                else:
+                    assert pr["ops0"][i] == want_ops, "host boundary (%s): op bytes differ from the oracle" % name
             assert np.array_equal(pr["reads0"][:k0], rs[:k0]), "host boundary (%s): reads not reverse-complemented like the oracle's" % name
         pcie["checked"] = ("every leg: best[], score, n_ops of all %d reads equal the device-resident path, the first %d equal the CPU "
                            "oracle; op bytes and reverse-complemented reads of the first %d reads equal the oracle's" % (n, sample_n, min(64, sample_n)))

@@ -135,10 +135,15 @@ typedef struct lrm_map_options {
     uint32_t sub_batches;      /*   seed sub-batches per pass, */
     uint32_t group_subs;       /*   sub-batches per extension group */
     uint32_t bs_waves;         /* tests: cap on the resident wavefronts of the bit-sliced kernel (forces lane refills) */
+    uint32_t cigar_text;       /* 1 (implies dense_results): cig_out[i].cigar points to the NUL-terminated run-length CIGAR TEXT
+                                  parse_cigar would print from the op bytes (alnmain.c:497-498; '=' and 'X' columns as M, "*"
+                                  for a read without an alignment) instead of the op bytes themselves -- the run-length pass runs
+                                  on the device and ~0.45 instead of 1.1 bytes per read base cross the link.  n_cigar_op stays
+                                  the number of alignment columns. */
     uint32_t copy_threads;     /* memcpy team of the PAGEABLE paths (upload staging, result placement): 0 automatic (the host's CPU
                                   share / replicas, at most 8 -- what 24 Gbp/s through pageable buffers needs), else 1..16; a caller
                                   whose own threads need the cores (lrm_accaln's parser and formatter) says 1 or 2 */
-    uint32_t reserved[9];
+    uint32_t reserved[8];
 } lrm_map_options;
 void lrm_map_options_init(lrm_map_options *o);
 

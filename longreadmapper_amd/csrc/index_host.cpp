@@ -232,12 +232,12 @@ static int sa_build_bucketed(const PackedText &t, uint64_t L, lrm_ui40 *out, uin
 
     const int PB = L > (1ull << 26) ? 8 : (L > (1ull << 18) ? 5 : 2);     // bases of the distribution prefix
     const uint64_t NB = 1ull << (2 * PB);
-    const int nth = omp_get_max_threads();
+    const int nth = lrm_host_threads();        // the team size of the region below (the caller's OpenMP limit may differ)
     // histogram of prefixes (per-thread, merged)
     std::vector<uint64_t> cnt(NB + 1, 0);
     {
         std::vector<std::vector<uint64_t>> local((size_t) nth, std::vector<uint64_t>(NB, 0));
-#pragma omp parallel num_threads(lrm_host_threads())
+#pragma omp parallel num_threads(nth)
         {
             std::vector<uint64_t> &h = local[(size_t) omp_get_thread_num()];
 #pragma omp for schedule(static)

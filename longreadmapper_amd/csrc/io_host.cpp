@@ -536,9 +536,10 @@ extern "C" char *lrm_sam_header(const lrm_mta_entry *mta, int mta_len, long rg_i
 
 // SAM lines of reads [lo, hi) appended to s (alnmain.c:500-525 field for field).  No snprintf on the hot path: a 10 kbp
 // ONT read has ~2000 CIGAR runs.
+// cigar_is_text: cig[i].cigar is the NUL-terminated run-length text already (lrm_map_options.cigar_text), not op bytes.
 static void sam_format_range(const lrm_read_batch *reads, const lrm_mta_entry *mta, int mta_len, const lrm_cigar *cig,
                              const int *score, const lrm_seq_meta *meta, const int *meta_r, uint64_t lo, uint64_t hi,
-                             std::string &s) {
+                             std::string &s, bool cigar_is_text) {
     uint64_t est = 0;
     for (uint64_t i = lo; i < hi; ++i) est += 2ull * reads->lens[i] + 2ull * (cig[i].n_cigar_op > 0 ? (uint64_t) cig[i].n_cigar_op : 0) + 160;
     s.clear();
@@ -561,7 +562,9 @@ static void sam_format_range(const lrm_read_batch *reads, const lrm_mta_entry *m
         s += '\t';
         s.append(num, (size_t) put_uint(num, (uint64_t) mapq));
         s += '\t';
-        if (!unmapped && cig[i].n_cigar_op > 0) {
+        if (!unmapped && cig[i].n_cigar_op > 0 && cigar_is_text) {
+            s.append((const char *) cig[i].cigar);
+        } else if (!unmapped && cig[i].n_cigar_op > 0) {
             const size_t at = s.size();
             s.resize(at + 2 * (size_t) cig[i].n_cigar_op + 16);            // alnmain.c:497: a 2 * qlen buffer there
             const size_t w = rle_write(cig[i].cigar, cig[i].n_cigar_op, &s[at]);
@@ -583,14 +586,14 @@ static void sam_format_range(const lrm_read_batch *reads, const lrm_mta_entry *m
 // Every thread formats a contiguous range of reads into its own buffer.
 static void sam_format_parts(const lrm_read_batch *reads, const lrm_mta_entry *mta, int mta_len, const lrm_cigar *cig,
                              const int *score, const lrm_seq_meta *meta, const int *meta_r, uint64_t n, int nt,
-                             std::vector<std::string> &parts) {
+                             std::vector<std::string> &parts, bool cigar_is_text = false) {
     if (nt < 1) nt = 1;
     if ((uint64_t) nt > n) nt = n ? (int) n : 1;
     parts.resize((size_t) nt);
 #pragma omp parallel for schedule(static, 1) num_threads(nt)
     for (int t = 0; t < nt; ++t)
         sam_format_range(reads, mta, mta_len, cig, score, meta, meta_r, n * (uint64_t) t / (uint64_t) nt, n * (uint64_t) (t + 1) / (uint64_t) nt,
-                         parts[(size_t) t]);
+                         parts[(size_t) t], cigar_is_text);
 }
 
 extern "C" char *lrm_sam_format(const lrm_read_batch *reads, const lrm_mta_entry *mta, int mta_len,
@@ -722,7 +725,7 @@ extern "C" int lrm_accaln(const char *genome, const char *reads_path, const char
         const int io_threads = lrm_host_threads() > 2 ? lrm_host_threads() / 2 : 1;     // loader and writer share the host
         lrm_map_options mopt;
         lrm_map_options_init(&mopt);
-        mopt.dense_results = 1;
+        mopt.cigar_text = 1;                        // parse_cigar (alnmain.c:497-498) runs on the device: the SAM CIGAR text comes back
         mopt.copy_threads = 2;                      // the parser and the formatter need the cores
         // Pinning the batch buffers (0.2 s per GB to pin and to release, and the device stalls while the runtime pins)
         // pays from a few tens of Gbp on: reads files below 16 GiB run through pageable buffers.
@@ -788,7 +791,7 @@ extern "C" int lrm_accaln(const char *genome, const char *reads_path, const char
                     const uint64_t n = s->b.n;
                     const double t0 = now();
                     sam_format_parts(&s->b, hi.mta, hi.mta_len, s->cig.data(), s->score.data(), s->meta.data(), s->meta_r.data(), n,
-                                     io_threads, tb->parts);
+                                     io_threads, tb->parts, /* cigar_is_text */ true);
                     t_fmt += now() - t0;
                     if (verbose) fprintf(stderr, "[lrm accaln] %.3f formatted %llu reads in %.3f s\n", now() - t_upload, (unsigned long long) n, now() - t0);
                     total += n;

@@ -71,7 +71,7 @@ static const char *const k_env_names[] = {
     "LRM_SA_SAMPLED", "LRM_LC_LONG", "LRM_LC_PAIR", "LRM_LC_BYTES", "LRM_LCX_THRESHOLD",                        // index
     "LRM_GACT_IMPL", "LRM_SEED_ROUNDS", "LRM_HOST_DENSE", "LRM_HOST_SLICE", "LRM_HOST_SUBS",
     "LRM_HOST_GROUP", "LRM_BS_WAVES", "LRM_SS_ITEMS", "LRM_VOTE_VG", "LRM_VOTE_T1", "LRM_VOTE_U", "LRM_VOTE_LOAD",
-    "LRM_HOST_EXT_STREAMS", "LRM_HOST_SEED_STREAMS", "LRM_HOST_VERBOSE", "LRM_VOTE_FAST", "LRM_HOST_SLOTS"};
+    "LRM_HOST_EXT_STREAMS", "LRM_HOST_SEED_STREAMS", "LRM_HOST_VERBOSE", "LRM_VOTE_FAST", "LRM_HOST_SLOTS", "LRM_SS_PAD"};
 static_assert(sizeof(k_env_names) / sizeof(k_env_names[0]) <= LrmEnv::MAXV, "LrmEnv too small");
 
 void lrm_env_snapshot(LrmEnv *e) {
@@ -128,7 +128,8 @@ void lrm_resolve_map_tune(const lrm_map_options *opt, const LrmEnv &env, LrmMapT
     lrm_map_options_init(&o);
     if (opt) memcpy(&o, opt, opt->struct_size && opt->struct_size < sizeof(o) ? opt->struct_size : sizeof(o));
     memset(t, 0, sizeof(*t));
-    t->dense = o.dense_results != 0;
+    t->cigar_text = o.cigar_text != 0;
+    t->dense = o.dense_results != 0 || t->cigar_text;
     t->gact_impl = o.gact_impl; t->seed_rounds = o.seed_rounds;
     t->slice_reads = o.slice_reads; t->sub_batches = o.sub_batches; t->group_subs = o.group_subs; t->bs_waves = o.bs_waves;
     t->copy_threads = o.copy_threads <= 16 ? o.copy_threads : 16;
@@ -138,12 +139,13 @@ void lrm_resolve_map_tune(const lrm_map_options *opt, const LrmEnv &env, LrmMapT
     long long v;
     if (env.get("LRM_GACT_IMPL", &v)) t->gact_impl = (int) v;
     if (env.get("LRM_SEED_ROUNDS", &v)) t->seed_rounds = (int) v;
-    if (env.get("LRM_HOST_DENSE", &v)) t->dense = v != 0;
+    if (env.get("LRM_HOST_DENSE", &v)) t->dense = v != 0 || t->cigar_text;
     if (env.get("LRM_HOST_SLICE", &v) && v >= 1) t->slice_reads = (uint32_t) v;
     if (env.get("LRM_HOST_SUBS", &v) && v >= 1) t->sub_batches = (uint32_t) v;
     if (env.get("LRM_HOST_GROUP", &v) && v >= 1) t->group_subs = (uint32_t) v;
     if (env.get("LRM_BS_WAVES", &v) && v >= 1) t->bs_waves = (uint32_t) v;
     if (env.get("LRM_SS_ITEMS", &v) && (v == 1024 || v == 2048 || v == 4096)) t->ss_items = (uint32_t) v;
+    if (env.get("LRM_SS_PAD", &v) && v >= 0 && v <= 60000) t->ss_lds_pad = (uint32_t) v;
     if (env.get("LRM_VOTE_VG", &v) && v >= 1 && v <= 64) t->vote_vg = (uint32_t) v;
     if (env.get("LRM_VOTE_T1", &v) && v >= 0 && v <= LRM_VOTE_T1_LIMIT) t->vote_t1 = (uint32_t) v;
     if (env.get("LRM_VOTE_U", &v)) t->vote_u = (uint32_t) v;

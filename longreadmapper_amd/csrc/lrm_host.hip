@@ -105,7 +105,7 @@ constexpr int N_RING = 4;
 constexpr int N_SEED_STREAMS = 3;
 constexpr int N_EXT_STREAMS = 4;
 constexpr int N_SLOTS = 3;            // upper bound on the batches (slices) in flight per replica; n_slots of them are used
-struct DevSet { DevSlot reads, lens, best, store, nops, score, meta, mr; };
+struct DevSet { DevSlot reads, lens, best, store, nops, score, meta, mr, tlen; };
 
 // device-side resources of one slice in flight
 struct Slot {
@@ -264,6 +264,104 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t *__restric
         else for (uint32_t e = 0; o + e < l; ++e) w[e >> 2] |= (uint32_t) s[o + e] << (8 * (e & 3));
         *reinterpret_cast<uint4 *>(d + o) = make_uint4(w[0], w[1], w[2], w[3]);
     }
+}
+
+// Run-length CIGAR text on the device (what parse_cigar prints, alnmain.c:497-498: '=' and 'X' columns as M): one
+// workgroup per read walks the op bytes 4096 columns at a time; a run is printed where it ENDS, its start comes from a
+// prefix maximum of the run starts, its place in the text from a prefix sum of the bytes the earlier runs print.
+// WRITE = false: only the text length (tlen[row]); WRITE = true: the text at dense + off[row], NUL-terminated.
+// Reads without an alignment (no ops, locus outside every sequence, score -1) print "*".
+__device__ __forceinline__ uint32_t op_class(uint32_t b) { return (b == '=' || b == 'X') ? (uint32_t) 'M' : b; }
+__device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
+    return v < 10 ? 1u : v < 100 ? 2u : v < 1000 ? 3u : v < 10000 ? 4u : v < 100000 ? 5u : v < 1000000 ? 6u : v < 10000000 ? 7u : 10u;
+}
+template <bool IS_MAX>
+__device__ __forceinline__ int block_excl_scan(int v, int *s_w, int *total) {       // exclusive scan over 256 threads (max with -1 / sum with 0)
+    const int lane = (int) (threadIdx.x & 63u), wave = (int) (threadIdx.x >> 6);
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d, 64);
+        if (lane >= d) x = IS_MAX ? (y > x ? y : x) : x + y;
+    }
+    __syncthreads();                                               // s_w of the previous scan has been read
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    int before = IS_MAX ? -1 : 0, all = IS_MAX ? -1 : 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int t = s_w[w];
+        all = IS_MAX ? (t > all ? t : all) : all + t;
+        if (w < wave) before = IS_MAX ? (t > before ? t : before) : before + t;
+    }
+    int excl = __shfl_up(x, 1, 64);
+    if (lane == 0) excl = IS_MAX ? -1 : 0;
+    *total = all;
+    return IS_MAX ? (excl > before ? excl : before) : excl + before;
+}
+template <bool WRITE>
+__global__ __launch_bounds__(256) void cigar_text_kernel(const uint8_t *__restrict__ store, uint64_t pitch, const int32_t *__restrict__ n_ops,
+                                                         const int32_t *__restrict__ score, const int32_t *__restrict__ meta_r,
+                                                         uint32_t *__restrict__ tlen, const uint64_t *__restrict__ off,
+                                                         uint8_t *__restrict__ dense, uint64_t rows) {
+    __shared__ int s_w[4];
+    const uint64_t row = blockIdx.x;
+    if (row >= rows) return;
+    const int n = n_ops[row];
+    const bool none = n <= 0 || meta_r[row] == 0 || score[row] == -1;
+    uint8_t *out = WRITE ? dense + off[row] : nullptr;
+    if (none) {
+        if (threadIdx.x == 0) { if (WRITE) { out[0] = '*'; out[1] = 0; } else tlen[row] = 1; }
+        return;
+    }
+    const uint8_t *ops = store + row * pitch;
+    int carry_start = 0, carry_out = 0;
+    for (int base = 0; base < n; base += 4096) {
+        const int c0 = base + (int) threadIdx.x * 16;
+        uint32_t cl[18];                                           // classes of columns c0 - 1 .. c0 + 16 (0 = outside the read)
+#pragma unroll
+        for (int k = 0; k < 18; ++k) {
+            const int col = c0 - 1 + k;
+            cl[k] = col >= 0 && col < n ? op_class(ops[col]) : 0u;
+        }
+        int last_start = -1;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (c0 + k < n && cl[k + 1] != cl[k]) last_start = c0 + k;
+        int any_start;
+        const int before = block_excl_scan<true>(last_start, s_w, &any_start);
+        const int open = before >= 0 ? before : carry_start;       // start of the run that is open at my first column
+        int bytes = 0, cs = open;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int col = c0 + k;
+            if (col < n) {
+                if (cl[k + 1] != cl[k]) cs = col;
+                if (cl[k + 2] != cl[k + 1]) bytes += (int) dec_digits((uint32_t) (col - cs + 1)) + 1;
+            }
+        }
+        int chunk_bytes;
+        int o = carry_out + block_excl_scan<false>(bytes, s_w, &chunk_bytes);
+        if (WRITE) {
+            cs = open;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int col = c0 + k;
+                if (col < n) {
+                    if (cl[k + 1] != cl[k]) cs = col;
+                    if (cl[k + 2] != cl[k + 1]) {
+                        uint32_t len = (uint32_t) (col - cs + 1);
+                        const int nd = (int) dec_digits(len);
+                        for (int d = nd - 1; d >= 0; --d) { out[o + d] = (uint8_t) ('0' + len % 10u); len /= 10u; }
+                        out[o + nd] = (uint8_t) cl[k + 1];
+                        o += nd + 1;
+                    }
+                }
+            }
+        }
+        carry_out += chunk_bytes;
+        if (any_start >= 0) carry_start = any_start;
+    }
+    if (threadIdx.x == 0) { if (WRITE) out[carry_out] = 0; else tlen[row] = (uint32_t) carry_out; }
 }
 
 // dense device buffer -> the caller's memory through the context's ring of pinned chunks: contiguous DMA pieces, every
@@ -457,7 +555,8 @@ int plan_and_issue(LrmHostCtx &c, SliceJob &sj) {
     DevSet &d = S.dev;
     if (d.reads.ensure(n * j.stride) || d.lens.ensure(n * 4) || d.best.ensure(n * sizeof(lrm_entry))) { lrm_set_error("device allocation failed"); return -1; }
     if ((j.mode & DO_EXTEND) && (d.store.ensure(n * dstride) || d.nops.ensure(n * 4) || d.score.ensure(n * 4) ||
-                                  d.meta.ensure(n * sizeof(lrm_seq_meta)) || d.mr.ensure(n * 4))) { lrm_set_error("device allocation failed"); return -1; }
+                                  d.meta.ensure(n * sizeof(lrm_seq_meta)) || d.mr.ensure(n * 4) ||
+                                  (mt.cigar_text && d.tlen.ensure(n * 4)))) { lrm_set_error("device allocation failed"); return -1; }
     // (the dense result buffers and offset tables at their worst-case size for a unit, so that the collector never
     //  reallocates -- a hipFree would drain the whole device -- while other work is in flight)
     if (j.mode & DO_EXTEND)
@@ -492,6 +591,12 @@ int plan_and_issue(LrmHostCtx &c, SliceJob &sj) {
                                   sj.max_len, (const lrm_entry *) d.best.p + u.off, j.gp, (uint8_t *) d.store.p + u.off * dstride, dstride,
                                   (int32_t *) d.nops.p + u.off, (int32_t *) d.score.p + u.off, (lrm_seq_meta *) d.meta.p + u.off,
                                   (int32_t *) d.mr.p + u.off, mt, c.ext[xs])) return -1;
+            if (mt.cigar_text) {                                               // length of every read's run-length CIGAR text
+                hipLaunchKernelGGL(cigar_text_kernel<false>, dim3((uint32_t) u.m), dim3(256), 0, c.ext[xs], (const uint8_t *) d.store.p + u.off * dstride, dstride,
+                                   (const int32_t *) d.nops.p + u.off, (const int32_t *) d.score.p + u.off, (const int32_t *) d.mr.p + u.off,
+                                   (uint32_t *) d.tlen.p + u.off, (const uint64_t *) nullptr, (uint8_t *) nullptr, u.m);
+                HIPCHK(hipGetLastError());
+            }
             HIPCHK(hipEventRecord(S.ev_ext[g], c.ext[xs]));
         }
         if (closes) {
@@ -522,12 +627,15 @@ int collect(LrmHostCtx &c, SliceJob &sj, size_t g) {
     int32_t *h_nops = (int32_t *) (hs + m * 48), *h_score = h_nops + m, *h_mr = h_score + m;   // 3 x 4
     uint32_t *h_len = (uint32_t *) (h_mr + m);                       // 2 x 4
     uint64_t *h_off = (uint64_t *) (hs + m * 72);                    // 2 x 8  (8-byte aligned: o*96 + m*72)
+    uint32_t *h_tlen = (uint32_t *) (hs + m * 88);                   // 4  (cigar_text)
+    const bool text = sj.mt.cigar_text != 0 && (j.mode & DO_EXTEND);
     if (j.mode & DO_SEED) HIPCHK(hipMemcpyAsync(h_best, (const lrm_entry *) d.best.p + o, m * sizeof(lrm_entry), hipMemcpyDeviceToHost, c.down));
     if (j.mode & DO_EXTEND) {
         HIPCHK(hipMemcpyAsync(h_nops, (const int32_t *) d.nops.p + o, m * 4, hipMemcpyDeviceToHost, c.down));
         HIPCHK(hipMemcpyAsync(h_score, (const int32_t *) d.score.p + o, m * 4, hipMemcpyDeviceToHost, c.down));
         HIPCHK(hipMemcpyAsync(h_meta, (const lrm_seq_meta *) d.meta.p + o, m * sizeof(lrm_seq_meta), hipMemcpyDeviceToHost, c.down));
         HIPCHK(hipMemcpyAsync(h_mr, (const int32_t *) d.mr.p + o, m * 4, hipMemcpyDeviceToHost, c.down));
+        if (text) HIPCHK(hipMemcpyAsync(h_tlen, (const uint32_t *) d.tlen.p + o, m * 4, hipMemcpyDeviceToHost, c.down));
     }
     HIPCHK(hipEventRecord(c.ev_small, c.down));
     if (wait_event(c.ev_small)) return -1;
@@ -549,9 +657,15 @@ int collect(LrmHostCtx &c, SliceJob &sj, size_t g) {
     uint64_t total_ops = 0, total = 0;
     for (uint64_t i = 0; i < m; ++i) {
         const uint64_t cap = j.store_stride;
-        h_len[i] = h_nops[i] > 0 ? (uint32_t) ((uint64_t) h_nops[i] < cap ? (uint64_t) h_nops[i] : cap) : 0u;
+        if (text) h_len[i] = h_tlen[i] + 1u;                                  // the text and its NUL
+        else h_len[i] = h_nops[i] > 0 ? (uint32_t) ((uint64_t) h_nops[i] < cap ? (uint64_t) h_nops[i] : cap) : 0u;
         h_off[i] = total_ops;
         total_ops += ((uint64_t) h_len[i] + 15) & ~15ull;
+    }
+    if (text && total_ops > m * j.store_stride) {
+        lrm_set_error("run-length CIGAR text of a group (%llu bytes) does not fit the %llu bytes of its rows in store_mem",
+                      (unsigned long long) total_ops, (unsigned long long) (m * j.store_stride));
+        return -3;
     }
     total = total_ops;
     uint64_t n_rev = 0;
@@ -575,7 +689,10 @@ int collect(LrmHostCtx &c, SliceJob &sj, size_t g) {
         if (n_rev)
             hipLaunchKernelGGL(pack_rows_kernel, dim3((uint32_t) m, gy_rd ? gy_rd : 1), dim3(256), 0, c.down, d_reads, j.stride,
                                d_len + m, d_off + m, dn, m);
-        if (total_ops)
+        if (total_ops && text)
+            hipLaunchKernelGGL(cigar_text_kernel<true>, dim3((uint32_t) m), dim3(256), 0, c.down, d_store, dstride, (const int32_t *) d.nops.p + o,
+                               (const int32_t *) d.score.p + o, (const int32_t *) d.mr.p + o, (uint32_t *) nullptr, (const uint64_t *) d_off, dn, m);
+        else if (total_ops)
             hipLaunchKernelGGL(pack_rows_kernel, dim3((uint32_t) m, gy_ops ? gy_ops : 1), dim3(256), 0, c.down, d_store, dstride,
                                d_len, d_off, dn, m);
         HIPCHK(hipGetLastError());
@@ -892,7 +1009,7 @@ void lrm_host_ctx_free(lrm_index *idx) {
         for (int s = 0; s < N_EXT_STREAMS; ++s) if (S.ws_ext[s]) lrm_workspace_free(S.ws_ext[s]);
         DevSet &d = S.dev;
         d.reads.release(); d.lens.release(); d.best.release(); d.store.release();
-        d.nops.release(); d.score.release(); d.meta.release(); d.mr.release();
+        d.nops.release(); d.score.release(); d.meta.release(); d.mr.release(); d.tlen.release();
         for (int b = 0; b < 2; ++b) { S.dense[b].release(); S.offs[b].release(); if (S.ev_dense[b]) (void) hipEventDestroy(S.ev_dense[b]); }
         S.h_small.release();
     }

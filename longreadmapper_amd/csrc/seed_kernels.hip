@@ -1449,7 +1449,8 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
                                : ss_items == 1024u ? seed_search_kernel<1024, false> : ss_items == 4096u ? seed_search_kernel<4096, false> : seed_search_kernel<2048, false>;
         if (ws->counting) bpr = (uint32_t) (((uint64_t) np * cap_q + 2047) / 2048);
         if (ws->counting) blocks = n * bpr;
-        hipLaunchKernelGGL(sk, dim3((uint32_t) blocks), dim3(256), 0, stream, idx->view,
+        // (mt.ss_lds_pad: extra dynamic LDS per workgroup, i.e. fewer resident workgroups per CU -- see DESIGN 5)
+        hipLaunchKernelGGL(sk, dim3((uint32_t) blocks), dim3(256), mt.ss_lds_pad, stream, idx->view,
                            ws->d_reads2, wpr, d_lens, dec, n, (int) seed_len, thres, lo, hi, cap_q, bpr,
                            ws->d_rec, ws->d_recq, ws->d_cnt, ws->d_hcount, ws->d_counters);
         lrm_time_end(ws, stream);

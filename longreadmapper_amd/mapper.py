@@ -74,8 +74,8 @@ def pinned_free(arr):
 class PendingBatch:
     """A batch submitted with map_batch_submit: wait() blocks until its results are in the caller's arrays."""
 
-    def __init__(self, ticket, keep, n, dense):
-        self.ticket, self._keep, self.n, self.dense = ticket, keep, n, dense
+    def __init__(self, ticket, keep, n, dense, text=False):
+        self.ticket, self._keep, self.n, self.dense, self.text = ticket, keep, n, dense, text
 
     def wait(self):
         t, self.ticket = self.ticket, None
@@ -88,7 +88,22 @@ class PendingBatch:
         if self.dense:          # cig[i].cigar = store_mem + off[i]
             ptr = np.ctypeslib.as_array(C.cast(cig, C.POINTER(C.c_uint64)), shape=(max(n, 1), 2))[:n, 0]
             out["ops_off"] = (ptr - np.uint64(store.ctypes.data)).astype(np.int64)
+        out["is_text"] = self.text   # cig[i].cigar -> NUL-terminated run-length CIGAR text: text_of(res, i)
         return out
+
+
+def text_of(res, i):
+    """Run-length CIGAR text of read i from a map_batch result in the cigar_text layout."""
+    assert res.get("is_text")
+    flat = res["ops"].reshape(-1)
+    o = int(res["ops_off"][i])
+    chunk = 64
+    while True:
+        b = bytes(flat[o:o + chunk])
+        z = b.find(b"\0")
+        if z >= 0:
+            return b[:z]
+        chunk *= 4
 
 
 def ops_of(res, i):
@@ -124,8 +139,9 @@ def map_batch_submit(index, reads, lens, seed_len=DEFAULT_SEED_LEN, thres=DEFAUL
                                    C.cast(cig, C.c_void_p), store.ctypes.data, store_stride, score.ctypes.data,
                                    meta.ctypes.data, meta_r.ctypes.data, C.byref(opt) if opt is not None else None,
                                    C.byref(ticket)), "lrm_map_batch_submit")
-    dense = bool(opt.dense_results) if opt is not None else False
-    return PendingBatch(ticket, (best, store, cig, score, meta, meta_r, reads, lens), n, dense)
+    text = bool(opt.cigar_text) if opt is not None else False
+    dense = (bool(opt.dense_results) or text) if opt is not None else False
+    return PendingBatch(ticket, (best, store, cig, score, meta, meta_r, reads, lens), n, dense, text)
 
 
 def map_batch(index, reads, lens, seed_len=DEFAULT_SEED_LEN, thres=DEFAULT_THRES, gact=DEFAULT_GACT, store=None,

@@ -100,6 +100,67 @@ def test_two_batches_in_flight(ont, opts, pinned):
                 mapper.pinned_free(st)
 
 
+@pytest.mark.parametrize("opts", [{"cigar_text": 1}, {"cigar_text": 1, "slice_reads": 11, "sub_batches": 2, "group_subs": 1}])
+@pytest.mark.parametrize("pinned", [False, True])
+def test_cigar_text_layout(ont, opts, pinned):
+    """lrm_map_options.cigar_text: parse_cigar (alnmain.c:497-498) on the device -- cig[i].cigar points to the
+    NUL-terminated run-length text of the read's op bytes ('=' and 'X' columns as M), "*" for a read without an
+    alignment; everything else as in the other layouts."""
+    import sam_ref
+    sc, di, oi, best, ext, r_cpu = ont
+    n, stride = sc["reads"].shape
+    r = mapper.pinned_empty((n, stride)) if pinned else np.empty((n, stride), dtype=np.uint8)
+    st = mapper.pinned_empty((n, (2 * (stride - 1) + 15) // 16 * 16)) if pinned else None
+    try:
+        r[:] = sc["reads"]
+        got = mapper.map_batch(di, r, sc["lens"], sc["seed_len"], sc["thres"], store=st, options=opts)
+        assert np.array_equal(got["best"], best) and np.array_equal(got["score"], ext["score"]) and np.array_equal(got["n_ops"], ext["n_ops"])
+        assert np.array_equal(got["meta_r"], ext["meta_r"]) and np.array_equal(r, r_cpu)
+        for i in range(n):
+            k = int(ext["n_ops"][i])
+            none = k <= 0 or ext["meta_r"][i] == 0 or ext["score"][i] == -1
+            assert mapper.text_of(got, i).decode() == ("*" if none else sam_ref.rle(bytes(ext["ops"][i, :k]))), i
+    finally:
+        if pinned:
+            mapper.pinned_free(r)
+            mapper.pinned_free(st)
+
+
+def test_cigar_text_of_long_and_odd_runs(gpu):
+    """The device's run-length pass on op strings that cross its 4096-column chunks and its 16-column lanes with runs of
+    every length: identical reads (one run of thousands of '='), a read with a long insertion, reads of 1..40 bases."""
+    import sam_ref
+    ref = synth.reference(60_000, seed=3)
+    hi = index.HostIndex.build([ref], hlen=8)
+    di = index.DeviceIndex.upload(hi, gpu)
+    oi = orc.OracleIndex.from_host_index(hi)
+    try:
+        lens = [9000, 8191, 8192, 8193, 4096, 4097, 12000] + list(range(21, 41))
+        n, mx = len(lens), max(lens)
+        reads = np.zeros((n, mx + 1), dtype=np.uint8)
+        rng = np.random.default_rng(1)
+        for i, l in enumerate(lens):
+            p0 = 1000 + 37 * i
+            seq = ref[p0:p0 + l].copy()
+            if i == 6:                                    # a 3000-base insertion in the middle: a long run of I
+                seq[4000:7000] = rng.choice(list(b"ACGT"), size=3000)
+            reads[i, :l] = seq
+        lens = np.array(lens, dtype=np.uint32)
+        want_best, _ = oi.seed_batch(reads, lens)
+        rc = reads.copy()
+        want = oi.extend_batch(rc, lens, want_best)
+        rg = reads.copy()
+        got = mapper.map_batch(di, rg, lens, options={"cigar_text": 1})
+        assert np.array_equal(got["best"], want_best) and np.array_equal(got["n_ops"], want["n_ops"])
+        for i in range(n):
+            k = int(want["n_ops"][i])
+            none = k <= 0 or want["meta_r"][i] == 0 or want["score"][i] == -1
+            assert mapper.text_of(got, i).decode() == ("*" if none else sam_ref.rle(bytes(want["ops"][i, :k]))), i
+        assert mapper.text_of(got, 0) == b"9000M"
+    finally:
+        di.close()
+
+
 def test_dense_results_need_an_aligned_stride(ont):
     sc, di, oi, best, ext, r_cpu = ont
     r = sc["reads"].copy()
