@@ -813,7 +813,7 @@ extern "C" void lrm_workspace_free(lrm_workspace *ws) {
     if (!ws) return;
     (void) hipSetDevice(ws->device);
     (void) hipFree(ws->d_reads2); (void) hipFree(ws->d_rec); (void) hipFree(ws->d_phase); (void) hipFree(ws->d_decided);
-    (void) hipFree(ws->d_hcount); (void) hipFree(ws->d_counters); (void) hipFree(ws->d_recq); (void) hipFree(ws->d_cnt); (void) hipFree(ws->d_kc_key); (void) hipFree(ws->d_kc_ord); (void) hipFree(ws->d_redo); (void) hipFree(ws->d_big);
+    (void) hipFree(ws->d_hcount); (void) hipFree(ws->d_counters); (void) hipFree(ws->d_recq); (void) hipFree(ws->d_cnt); (void) hipFree(ws->d_kc_key); (void) hipFree(ws->d_kc_ord); (void) hipFree(ws->d_redo); (void) hipFree(ws->d_big); (void) hipFree(ws->d_gtab); (void) hipFree(ws->d_glock);
     (void) hipFree(ws->d_qpl); (void) hipFree(ws->d_rflags);
     (void) hipFree(ws->d_ckpt); (void) hipFree(ws->d_codes); (void) hipFree(ws->d_ncodes);
     if (ws->h_err) (void) hipHostFree((void *) ws->h_err);
@@ -853,6 +853,14 @@ int lrm_workspace_create_parts(lrm_workspace **out, lrm_index *idx, uint64_t n_m
     ws->qpl_wpr = lrm_bs_planar_words(max_len);
     ws->codes_cw = lrm_bs_code_words(max_len);
     ws->parts = parts;
+    {   // pool of global vote tables: a slice holds 2^k >= 2 x the most hits one (read, phase) item can have
+        const uint64_t hmax = (uint64_t) ws->cap_q * (thres > 1 ? thres - 1 : 1);
+        uint64_t gs = 1024;
+        while (gs < 2 * hmax && gs < (1ull << 26)) gs <<= 1;
+        uint64_t nsl = (256ull << 20) / (gs * 16);
+        ws->g_slots = (uint32_t) gs;
+        ws->g_slices = (uint32_t) (nsl < 2 ? 2 : nsl > 32 ? 32 : nsl);
+    }
     struct { void **p; uint64_t bytes; int part; } allocs[] = {
         {(void **) &ws->d_reads2, n_max * ws->words_per_read * 8 + 128, LRM_WS_SEED},   // + slack: seed_search's scalar window loads reach 6 words
 
@@ -863,6 +871,8 @@ int lrm_workspace_create_parts(lrm_workspace **out, lrm_index *idx, uint64_t n_m
         {(void **) &ws->d_kc_ord, (uint64_t) LRM_VOTE_GRID * LRM_VOTE_KC_CAP * 4, LRM_WS_SEED},
         {(void **) &ws->d_redo, n_max * (uint64_t) ws->P * 8, LRM_WS_SEED},
         {(void **) &ws->d_big, n_max * (uint64_t) ws->P * 8, LRM_WS_SEED},
+        {(void **) &ws->d_gtab, (uint64_t) ws->g_slices * ws->g_slots * 16, LRM_WS_SEED},
+        {(void **) &ws->d_glock, 64 * 4, LRM_WS_SEED},
         {(void **) &ws->d_phase, n_max * (uint64_t) ws->P * sizeof(LrmPhaseRes), LRM_WS_SEED},
         {(void **) &ws->d_decided, n_max, LRM_WS_SEED},
         {(void **) &ws->d_hcount, n_max * (uint64_t) ws->P * 4, LRM_WS_SEED},
@@ -883,6 +893,7 @@ int lrm_workspace_create_parts(lrm_workspace **out, lrm_index *idx, uint64_t n_m
         ws->bytes += a.bytes;
     }
     if (hipMemset(ws->d_counters, 0, sizeof(LrmDevCounters)) != hipSuccess) { lrm_workspace_free(ws); lrm_set_error("memset failed"); return -1; }
+    if (ws->d_glock && hipMemset(ws->d_glock, 0, 64 * 4) != hipSuccess) { lrm_workspace_free(ws); lrm_set_error("memset failed"); return -1; }
     {   // error word: host-coherent pinned memory the kernels store to (never reset by a launch)
         void *h = nullptr, *d = nullptr;
         if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||

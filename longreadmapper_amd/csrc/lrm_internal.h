@@ -196,6 +196,9 @@ struct lrm_workspace {
     uint32_t *d_kc_ord;      //              ... and their order keys
     uint64_t *d_redo;        // items the fast vote kernels left to the exact one (n_max * P)
     uint64_t *d_big;         // items the wavefront form left to the workgroup form (n_max * P)
+    uint64_t *d_gtab;        // pool of global-memory vote tables for items beyond the key scratch: g_slices x {key[g_slots], cf[g_slots]}
+    uint32_t *d_glock;       // one lock word per slice
+    uint32_t g_slices, g_slots;
     LrmPhaseRes *d_phase;    // n_max * P
     uint8_t *d_decided;      // n_max
     uint32_t *d_hcount;      // SA hits (sum of rr) per (read, phase): routes an item to its vote-table tier

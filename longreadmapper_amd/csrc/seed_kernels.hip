@@ -657,6 +657,34 @@ __device__ __forceinline__ Top2 table_top2(const VoteTable &t, uint32_t tid) {
     return r;
 }
 
+// the same over a table in GLOBAL memory (the one-pass path of very large items): the counts were written by atomics
+// through L2, and a slice of the pool is reused by later items, so the scan reads past the L1 (agent-scope loads)
+__device__ __forceinline__ Top2 table_top2_global(const VoteTable &t, uint32_t tid) {
+    uint64_t k1 = 0, k2 = 0;
+    uint32_t s1 = 0, s2 = 0;
+    for (uint32_t s = tid; s < t.slots; s += 256) {
+        const uint64_t k = __hip_atomic_load(&t.cf[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k > k1) { k2 = k1; s2 = s1; k1 = k; s1 = s; }
+        else if (k > k2) { k2 = k; s2 = s; }
+    }
+    const uint64_t m1 = wave_max_u64(k1);
+    const bool win = k1 == m1 && (m1 >> 32) != 0;
+    const uint64_t m2 = wave_max_u64(win ? k2 : k1);
+    Top2 r;
+    r.k1 = (m1 >> 32) ? m1 : 0; r.k2 = (m2 >> 32) ? m2 : 0; r.s1 = 0; r.s2 = 0;
+    if (r.k1) {
+        const unsigned long long b = __ballot(k1 == m1);
+        r.s1 = (uint32_t) __builtin_amdgcn_readlane((int) s1, (int) __builtin_ctzll(b));
+    }
+    if (r.k2) {
+        const bool has = (win ? k2 : k1) == m2;
+        const unsigned long long b = __ballot(has);
+        const int src = (int) __builtin_ctzll(b);
+        r.s2 = (uint32_t) __builtin_amdgcn_readlane((int) (win ? s2 : s1), src);
+    }
+    return r;
+}
+
 // survivor s of the hit h: off[s] <= h < off[s + 1]  (off: exclusive prefix of the staged survivors' hit counts,
 // strictly increasing because every survivor has at least one hit; cnt >= 1)
 // (Measured alternative for the wavefront tier [r2]: a marker byte where the hits of each staged seed begin + a DPP
@@ -792,17 +820,42 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
                                                 uint32_t iter, uint32_t P, uint32_t tbits, uint32_t slots, uint32_t limit,
                                                 BlockLds &L, uint32_t *s_wsum, Top2 *s_top, LrmPhaseRes *out,
                                                 uint32_t *err_word, uint32_t load, uint64_t *kc_key, uint32_t *kc_ord,
-                                                uint32_t kc_cap) {
+                                                uint32_t kc_cap, uint64_t *gtab, uint32_t *glock, uint32_t g_slices,
+                                                uint32_t g_slots, uint32_t *s_slice) {
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     const int lane = (int) (tid & 63);
     VoteTable t = {L.key, L.cf, slots};
-    const uint32_t passes = (H + limit - 1) / limit;
+    uint32_t passes = (H + limit - 1) / limit;
+    // Items with more hits than the key scratch holds (a read made of a 100-299-copy repeat family: up to
+    // cap_q * (thres - 1) hits per phase, 142 k for a 10 kbp read) would take H / 768 passes of H gathers each over
+    // the 1024-slot LDS table -- quadratic, minutes for a batch of such reads.  They vote in ONE pass into a table in
+    // global memory instead: the workgroup takes one of a few slices of a pool (a spin on a lock word: holders never
+    // wait for anyone, so it always comes free), clears 2^k >= 2 H slots, inserts with the same compare-and-swap
+    // protocol through L2, scans, gives the slice back.
+    const bool big = gtab != nullptr && H > kc_cap && 2ull * H <= (uint64_t) g_slots;
+    if (big) {
+        if (tid == 0) {
+            uint32_t got = 0xFFFFFFFFu;
+            for (uint32_t spin = 0; got == 0xFFFFFFFFu; ++spin) {
+                const uint32_t sl = (blockIdx.x + spin) % g_slices;
+                if (atomicCAS(&glock[sl], 0u, 1u) == 0u) got = sl;
+                else __builtin_amdgcn_s_sleep(32);
+            }
+            *s_slice = got;
+        }
+        __syncthreads();
+        uint32_t gs = 1024;
+        while (gs < 2 * H) gs <<= 1;
+        uint64_t *base = gtab + (uint64_t) (*s_slice) * 2ull * g_slots;
+        t.key = base; t.cf = base + g_slots; t.slots = gs;
+        passes = 1;
+    }
     // Items that need several passes (ultra-long reads: ~3500 hits, five passes): the first pass writes every hit's
     // {key, order key} to this workgroup's slice of a global scratch, and the later passes stream them back
     // (12 coalesced bytes per hit) instead of searching, gathering and subtracting again.
     // (from three passes on: with two, writing and re-reading 12 B per hit costs as much traffic as it saves)
     const bool cache = passes > 2 && H <= kc_cap;
-    {
+    if (!big) {
         const uint32_t per_pass = passes > 1 ? limit : H;
         const uint32_t eff = per_pass * 100u / load + 64;
         t.slots = eff < slots ? eff : slots;
@@ -810,6 +863,7 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
     PhaseTop best = {};
     for (uint32_t pass = 0; pass < passes; ++pass) {
         for (uint32_t s = tid; s < t.slots; s += 256) { t.key[s] = EMPTY_KEY; t.cf[s] = 0; }
+        if (big) { __threadfence(); __syncthreads(); }             // the cleared slots are in L2 before the first atomic of another thread
         bool ok = true;
         if (cache && pass > 0) {
             __syncthreads();                                   // table cleared
@@ -854,8 +908,9 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
         if (cache) __threadfence_block();                      // the scratch is read back by other threads of the workgroup
         }
         if (!ok) *(volatile uint32_t *) err_word = LRM_ERR_VOTE_OVERFLOW;   // host-coherent, sticky
+        if (big) __threadfence();
         __syncthreads();
-        const Top2 w = table_top2<256>(t, tid);                       // this wavefront's share of the table
+        const Top2 w = big ? table_top2_global(t, tid) : table_top2<256>(t, tid);                       // this wavefront's share of the table
         if (lane == 0) s_top[wave] = w;
         __syncthreads();
         if (tid == 0) {
@@ -879,7 +934,7 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
                 const uint64_t c = ck[x];
                 if (!c) continue;
                 const uint32_t cv = (uint32_t) (c >> 32), cf = 0xFFFFFFFFu - (uint32_t) c;
-                const uint64_t ky = t.key[cslot[x]], bk = ky >> 4;
+                const uint64_t ky = big ? __hip_atomic_load(&t.key[cslot[x]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t.key[cslot[x]], bk = ky >> 4;
                 if (c > r1k) {
                     nb.key2 = nb.key1; nb.bucket2 = nb.bucket1; nb.val2 = nb.val1; nb.first2 = nb.first1; r2k = r1k;
                     nb.key1 = ky; nb.bucket1 = bk; nb.val1 = cv; nb.first1 = cf; r1k = c;
@@ -892,6 +947,10 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
         __syncthreads();
     }
     if (tid == 0) write_phase(out, best);
+    if (big) {                                                     // the slice goes back to the pool
+        __syncthreads();
+        if (tid == 0) { __threadfence(); atomicExch(&glock[*s_slice], 0u); }
+    }
 }
 
 // ---- fast path: one wavefront per item, repeat-only buckets never enter the table ------------------------------------------
@@ -1245,13 +1304,15 @@ void vote_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
                                                    unsigned long long *ticket, uint64_t *__restrict__ kc_key_all,
                                                    uint32_t *__restrict__ kc_ord_all, uint32_t kc_cap,
                                                    LrmPhaseRes *__restrict__ phase_res, uint32_t *err_word,
-                                                   const uint64_t *__restrict__ list, const unsigned long long *__restrict__ list_n) {
+                                                   const uint64_t *__restrict__ list, const unsigned long long *__restrict__ list_n,
+                                                   uint64_t *gtab, uint32_t *glock, uint32_t g_slices, uint32_t g_slots) {
     __shared__ VoteLds lds;
     __shared__ uint32_t g_H[VG_MAX], g_cnt[VG_MAX], g_ph[VG_MAX];
     __shared__ uint64_t g_id[VG_MAX];
     __shared__ uint32_t s_wsum[12];
     __shared__ Top2 s_top[4];
     __shared__ unsigned long long s_grp;
+    __shared__ uint32_t s_slice;
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     const int lane = (int) (tid & 63);
     const uint32_t P = (uint32_t) seed_len + 1;
@@ -1299,7 +1360,8 @@ void vote_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec,
         if (H <= limit1) continue;
         const uint64_t id = g_id[g];
         vote_item_block<VOTE_U>(ix, rec + id * cap_q, recq + id * cap_q, g_cnt[g], H, g_ph[g], P, tbits, slots3,
-                        limit3, lds.b, s_wsum, s_top, &phase_res[id], err_word, load, kc_key, kc_ord, kc_cap);
+                        limit3, lds.b, s_wsum, s_top, &phase_res[id], err_word, load, kc_key, kc_ord, kc_cap, gtab, glock, g_slices,
+                        g_slots, &s_slice);
         __syncthreads();
     }
     __syncthreads();                                          // s_grp, g_* are rewritten by the next round
@@ -1459,6 +1521,7 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
         if (vblocks > LRM_VOTE_GRID) vblocks = LRM_VOTE_GRID;          // resident workgroups; groups of items go by ticket
         lrm_time_begin(ws, LRM_K_VOTE, stream);
         auto vk = vote_u == 2 ? vote_kernel<2> : vote_u == 8 ? vote_kernel<8> : vote_kernel<4>;
+        uint64_t *big_tab = mt.t3_limit ? nullptr : ws->d_gtab;      // (the overflow-forcing test knobs keep the LDS passes)
         if (mt.vote_fast) {
             // fast kernel over all items, then the exact kernel over the items it could not settle (its list)
             uint64_t fblocks = (items + 4 * FAST_CH - 1) / (4 * FAST_CH);
@@ -1478,13 +1541,13 @@ int lrm_launch_seed(lrm_index *idx, lrm_workspace *ws, const char *d_reads, uint
                                ws->d_cnt, ws->d_hcount, dec, n, (int) seed_len, lo, hi, cap_q, tbits, t3_slots, t3_limit,
                                vg, t1_limit, vote_load, &ws->d_counters->reserved[1 + round], ws->d_kc_key, ws->d_kc_ord,
                                (uint32_t) LRM_VOTE_KC_CAP, ws->d_phase, ws->d_err, (const uint64_t *) ws->d_redo,
-                               (const unsigned long long *) &ws->d_counters->vote_redo_n[round]);
+                               (const unsigned long long *) &ws->d_counters->vote_redo_n[round], big_tab, ws->d_glock, ws->g_slices, ws->g_slots);
         } else {
             hipLaunchKernelGGL(vk, dim3((uint32_t) vblocks), dim3(256), 0, stream, idx->view, ws->d_rec, ws->d_recq,
                                ws->d_cnt, ws->d_hcount, dec, n, (int) seed_len, lo, hi, cap_q, tbits, t3_slots, t3_limit,
                                vg, t1_limit, vote_load, &ws->d_counters->reserved[1 + round], ws->d_kc_key, ws->d_kc_ord,
                                (uint32_t) LRM_VOTE_KC_CAP, ws->d_phase, ws->d_err, (const uint64_t *) nullptr,
-                               (const unsigned long long *) nullptr);
+                               (const unsigned long long *) nullptr, big_tab, ws->d_glock, ws->g_slices, ws->g_slots);
         }
         lrm_time_end(ws, stream);
         lrm_time_begin(ws, LRM_K_DECIDE, stream);

@@ -440,21 +440,23 @@ def test_vote_wave_tier_at_its_limit(gpu, exact_only):
 def test_vote_key_scratch_at_its_capacity(gpu, exact_only):
     """An item with exactly LRM_VOTE_KC_CAP = 16384 hits (64 seeds x 256 copies of a tandem block): the multi-pass tier
     keeps the keys of such an item in its workgroup's slice of the key scratch, which is then full to the last entry
-    (22 passes over the 1024-slot table).  One more copy (257 x 64 hits) is past the capacity: the passes gather again."""
-    block = bytes(synth.reference(64 * 21, seed=3))
+    (22 passes over the 1024-slot table).  Past the capacity (257 x 64 and 250 x 130 hits) the item votes in one pass into
+    a table in global memory (a slice of the workspace's pool)."""
     flank = lambda s: bytes(synth.reference(700, seed=s))
-    for copies in (256, 257):
+    for copies, nseeds in ((256, 64), (257, 64), (250, 130)):       # 16384, 16448 and 32500 hits in the phase-0 item
+        block = bytes(synth.reference(nseeds * 21, seed=3))
         ref = np.frombuffer(flank(1) + block * copies + flank(2), dtype=np.uint8)
         hi = index.HostIndex.build([ref], hlen=8)
         read = block + bytes(synth.reference(30, seed=9))
-        reads = np.zeros((2, len(read) + 1), dtype=np.uint8)
-        reads[0, :len(read)] = np.frombuffer(read, dtype=np.uint8)
-        reads[1, :700] = np.frombuffer(flank(1), dtype=np.uint8)
-        lens = np.array([len(read), 700], dtype=np.uint32)
+        nrep = 80 if copies == 257 else 1           # more such items than the pool has slices (32): slices are handed on
+        reads = np.zeros((nrep + 1, len(read) + 1), dtype=np.uint8)
+        reads[:nrep, :len(read)] = np.frombuffer(read, dtype=np.uint8)
+        reads[nrep, :700] = np.frombuffer(flank(1), dtype=np.uint8)
+        lens = np.array([len(read)] * nrep + [700], dtype=np.uint32)
         oi, want, got = _seed_both(hi, reads, lens, gpu, vote_exact_only=exact_only)
         tr = oi.seed_read(read, 20, 300, trace=True)
-        assert sum(rr for j, rr, _, _ in tr["seeds"] if j % 21 == 0) == 64 * copies
-        assert np.array_equal(got, want), copies
+        assert sum(rr for j, rr, _, _ in tr["seeds"] if j % 21 == 0) == nseeds * copies
+        assert np.array_equal(got, want), (copies, nseeds)
 
 
 def test_exact_vote_kernel_alone_equals_the_fast_path(dev_indexes, map_options):
