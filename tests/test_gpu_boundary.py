@@ -302,6 +302,33 @@ def test_sampled_sa_locate_mode(gpu, name, ratio):
         di.close()
 
 
+@pytest.mark.parametrize("opts", [{"dense_results": 1}, {"cigar_text": 1}, {}])
+def test_group_handle_with_batches_in_flight(ont, gpu, opts):
+    """lrm_map_batch_submit on a multi-GPU group handle (three logical replicas on the one device): every batch is cut
+    by bases into one share per replica, each replica's issuer / collector threads run their share, one ticket completes
+    when all have; two batches in flight plus one queued, in every result layout -- byte-identical with one GPU."""
+    import sam_ref
+    sc, di, oi, best, ext, r_cpu = ont
+    dg = index.DeviceIndex.upload_multi(sc["hi"], [gpu] * 3)
+    try:
+        n = len(best)
+        bufs = [sc["reads"].copy() for _ in range(3)]
+        pend = [mapper.map_batch_submit(dg, b, sc["lens"], sc["seed_len"], sc["thres"], options=opts) for b in bufs]
+        for k in (2, 0, 1):
+            got = pend[k].wait()
+            assert np.array_equal(got["best"], best) and np.array_equal(bufs[k], r_cpu)
+            assert np.array_equal(got["score"], ext["score"]) and np.array_equal(got["n_ops"], ext["n_ops"])
+            if opts.get("cigar_text"):
+                for i in range(n):
+                    kk = int(ext["n_ops"][i])
+                    none = kk <= 0 or ext["meta_r"][i] == 0 or ext["score"][i] == -1
+                    assert mapper.text_of(got, i).decode() == ("*" if none else sam_ref.rle(bytes(ext["ops"][i, :kk]))), (k, i)
+            else:
+                _assert_ext_equal(_dense_rows(got) if opts.get("dense_results") else got, ext, n, "group, batch %d %s" % (k, opts))
+    finally:
+        dg.close()
+
+
 def test_suffix_array_values_beyond_32_bits(gpu):
     """GRCh38's .cat has 6.2 G rows: SA values need ui40.high (sa_use.h:17-29).  A small FM index whose SA values
     are all shifted by 2^33 + 2^36 pushes 37-bit values through lrm_index_upload (ui40 -> u64), the SA gathers,
