@@ -112,9 +112,12 @@ typedef struct lrm_index_options {
     uint32_t lc_entry_bytes;   /* entries of the long table: 0 automatic, 8, or 5 (pair-line layout only: 40 bytes per
                                   (k-1)-mer instead of 64 -- pair-line 17-mers of a GRCh38-sized text in 160 GiB; counts that
                                   do not fit the 40 - ceil(log2(rows)) count bits go through a side hash table) */
+    int32_t lc_core;           /* core table (texts of up to 2^25 rows, next to pair-line 16-mers): one 64-byte line per 13-mer holds
+                                  the entries of the 16-mers around it, the lookups of FOUR neighbouring read positions share it
+                                  (4 GiB): -1 automatic, 0 off, 1 on */
     uint32_t lc_count_bits;    /* tests: count bits of the 5-byte entries (0: 40 - ceil(log2(rows))); a small value sends
                                   ordinary repeats through the side hash table */
-    uint32_t reserved[8];
+    uint32_t reserved[7];
 } lrm_index_options;
 void lrm_index_options_init(lrm_index_options *o);
 

@@ -61,7 +61,7 @@ class GactParams(C.Structure):
 class IndexOptions(C.Structure):       # lrm_index_options
     _fields_ = [("struct_size", C.c_uint32), ("sa_sampled", C.c_int32), ("lc_long", C.c_int32),
                 ("lc_long_max", C.c_int32), ("lc_pair", C.c_int32), ("lcx_threshold", C.c_uint32),
-                ("lc_entry_bytes", C.c_uint32), ("lc_count_bits", C.c_uint32), ("reserved", C.c_uint32 * 8)]
+                ("lc_entry_bytes", C.c_uint32), ("lc_core", C.c_int32), ("lc_count_bits", C.c_uint32), ("reserved", C.c_uint32 * 7)]
 
 
 class MapOptions(C.Structure):         # lrm_map_options

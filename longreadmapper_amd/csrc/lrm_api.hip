@@ -68,7 +68,7 @@ static inline uint64_t align256(uint64_t x) { return (x + 255ull) & ~255ull; }
 // options: the caller's structs, then the LRM_* environment overrides as they stood when the handle was created
 // ------------------------------------------------------------------------------------------
 static const char *const k_env_names[] = {
-    "LRM_SA_SAMPLED", "LRM_LC_LONG", "LRM_LC_PAIR", "LRM_LC_BYTES", "LRM_LCX_THRESHOLD",                        // index
+    "LRM_SA_SAMPLED", "LRM_LC_LONG", "LRM_LC_PAIR", "LRM_LC_BYTES", "LRM_LC_CORE", "LRM_LCX_THRESHOLD",                        // index
     "LRM_GACT_IMPL", "LRM_SEED_ROUNDS", "LRM_HOST_DENSE", "LRM_HOST_SLICE", "LRM_HOST_SUBS",
     "LRM_HOST_GROUP", "LRM_BS_WAVES", "LRM_SS_ITEMS", "LRM_VOTE_VG", "LRM_VOTE_T1", "LRM_VOTE_U", "LRM_VOTE_LOAD",
     "LRM_HOST_EXT_STREAMS", "LRM_HOST_SEED_STREAMS", "LRM_HOST_VERBOSE", "LRM_VOTE_FAST", "LRM_HOST_SLOTS", "LRM_SS_PAD"};
@@ -94,6 +94,7 @@ extern "C" void lrm_index_options_init(lrm_index_options *o) {
     o->struct_size = (uint32_t) sizeof(*o);
     o->lc_long = -1;
     o->lc_pair = -1;
+    o->lc_core = -1;
 }
 extern "C" void lrm_map_options_init(lrm_map_options *o) {
     if (!o) return;
@@ -114,12 +115,14 @@ void lrm_resolve_index_tune(const lrm_index_options *opt, const LrmEnv &env, Lrm
     t->lc_long = o.lc_long; t->lc_long_max = o.lc_long_max; t->lc_pair = o.lc_pair;
     t->lc_entry_bytes = o.lc_entry_bytes == 5 || o.lc_entry_bytes == 8 ? (int) o.lc_entry_bytes : 0;
     t->lc_count_bits = o.lc_count_bits >= 2 && o.lc_count_bits <= 24 ? (int) o.lc_count_bits : 0;
+    t->lc_core = o.lc_core;
     t->lcx_threshold = o.lcx_threshold >= 1 && o.lcx_threshold <= 0xFFFFFFu ? o.lcx_threshold : 0xFFFFFFull;
     long long v;
     if (env.get("LRM_SA_SAMPLED", &v)) t->sa_ratio = valid_sa_ratio(v) ? (int) v : 1;
     if (env.get("LRM_LC_LONG", &v)) t->lc_long = (int) v;
     if (env.get("LRM_LC_PAIR", &v)) t->lc_pair = v != 0;
     if (env.get("LRM_LC_BYTES", &v) && (v == 5 || v == 8)) t->lc_entry_bytes = (int) v;
+    if (env.get("LRM_LC_CORE", &v)) t->lc_core = v != 0;
     if (env.get("LRM_LCX_THRESHOLD", &v) && v >= 1 && v <= 0xFFFFFFll) t->lcx_threshold = (uint64_t) v;
 }
 
@@ -489,6 +492,7 @@ static int make_handle(lrm_index **out, void *d_blob, uint64_t bytes, int device
     ix->view.sa_len = h.sa_len; ix->view.con_len = h.con_len;
     for (int i = 0; i < 4; ++i) ix->view.c4[i] = h.c4[i];
     ix->view.hlen = h.hlen; ix->view.mta_len = h.mta_len;
+    ix->view.core = nullptr;
     ix->view.lcl = nullptr; ix->view.hl = 0; ix->view.lcl_pair = 0; ix->view.lcl_kbits = 0; ix->view.lclx = nullptr; ix->view.lclx_mask = 0;
     ix->view.sa_shift = 0;
     for (uint64_t r = h.sa_ratio > 1 ? h.sa_ratio : 1; r > 1; r >>= 1) ix->view.sa_shift++;
@@ -802,6 +806,7 @@ extern "C" void lrm_index_free(lrm_index *idx) {
     lrm_bs_free_index(idx);
     if (idx->d_lcl) (void) hipFree(idx->d_lcl);
     if (idx->d_lclx) (void) hipFree(idx->d_lclx);
+    if (idx->d_core) (void) hipFree(idx->d_core);
     if (idx->owns_blob && idx->d_blob) (void) hipFree(idx->d_blob);
     delete idx;
 }

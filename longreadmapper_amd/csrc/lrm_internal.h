@@ -77,6 +77,8 @@ struct LrmIndexView {
     int32_t lcl_pair;         // long table in PAIR-LINE layout (seed_kernels.hip): the lookups of two neighbouring seeds share a 64-byte line
     int32_t lcl_kbits;        // 0: 8-byte entries (k | count << 40).  > 0: 5-BYTE entries, k in the low lcl_kbits bits, count above
                               // (all ones = look the hl-mer up in the side hash table lclx)
+    const uint64_t *core;     // optional CORE table of small texts (seed_kernels.hip): one 64-byte line per 13-mer holds the entries of
+                              // the 16-mers around it, so that the lookups of FOUR neighbouring read positions share a line; null = unused
     const uint64_t *lclx;     // side hash table of the 5-byte layout: {hl-mer code + 1, k | count << 40} pairs, open addressing
     uint64_t lclx_mask;       // slots - 1 (a power of two)
 };
@@ -94,7 +96,7 @@ struct LrmEnv {                     // the LRM_* variables as they stood when th
 void lrm_env_snapshot(LrmEnv *e);
 struct LrmIndexTune {
     int sa_ratio;                   // 1: full SA; 2..64: sampled
-    int lc_long, lc_long_max, lc_pair, lc_entry_bytes, lc_count_bits;
+    int lc_long, lc_long_max, lc_pair, lc_entry_bytes, lc_count_bits, lc_core;
     uint64_t lcx_threshold;
 };
 struct LrmMapTune {
@@ -117,6 +119,7 @@ struct lrm_index {
     LrmIndexView view;
     uint64_t *d_lcl;          // long lc table (owned; may be null)
     uint64_t *d_lclx;         // its side hash table in the 5-byte layout (owned; may be null)
+    uint64_t *d_core;         // core table (owned; may be null)
     uint64_t *d_cpl;          // planar 2-bit copy of the text for the bit-sliced GACT kernel (owned; may be null)
     int cpl_ok;               // text is pure ACGT (otherwise the byte kernels are used)
     uint64_t *d_sas;          // sampled-SA locate mode (csa_access, fmidx.c:315-331): SA rows i*sa_ratio (owned; may be null)

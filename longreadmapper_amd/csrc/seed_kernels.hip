@@ -129,7 +129,43 @@ __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t wi
                                              uint64_t &k, uint64_t &l, uint32_t *cnt = nullptr) {
     int left = seed_len - ix.hlen;
     bool looked_up = false;
-    if (ix.lcl && seed_len >= ix.hl) {
+    if (ix.core && seed_len >= 16) {
+        // CORE table (small texts): the 16-mers of read positions p0 .. p0 + 3 (p0 a multiple of 4) share the 13 bases
+        // [p0 + 3, p0 + 16) of their windows; the line of that 13-mer holds the entries of the text's 16-mers around it
+        // (eight 8-byte slots: k | count << 40 | tag << 56, tag = the window's role r = p & 3 and its 3 bases outside
+        // the core), so the four lanes read ONE line.  Slots fill from a tag-dependent home pair onwards (no deletions:
+        // an empty slot ends the search); a line that would need more than eight slots is all ones: such 16-mers take
+        // the pair-line table below.
+        const int left2 = seed_len - 16;
+        const uint64_t W = (win >> (2 * left2)) & 0xFFFFFFFFull;                        // the seed's last 16 bases, first base lowest
+        const uint32_t r = jpar & 3u;
+        const uint64_t corec = (W >> (2 * (3 - r))) & ((1ull << 26) - 1ull);
+        const uint32_t extra = (uint32_t) (W & ((1ull << (2 * (3 - r))) - 1ull)) | ((uint32_t) (W >> (2 * (16 - r))) << (2 * (3 - r)));
+        const uint32_t tag = r | (extra << 2);
+        const uint64_t *line = ix.core + corec * 8;
+        // The whole line in ONE round trip (four independent 16-byte requests to one 64-byte line), searched in registers.
+        // (Measured on the bench workload, ms per Gbp: no core table 15.4-15.7; a search walking the line pair by pair
+        //  from a tag-dependent home pair 17.3 -- every step is a dependent round trip for the whole wavefront; the first
+        //  half of the line, the second only when the first is full of other 16-mers 14.2 -- the repeat family's lines
+        //  are, and some lane of nearly every wavefront sits in one; the whole line at once 13.2.)
+        const ulonglong2 x0 = *reinterpret_cast<const ulonglong2 *>(line), x1 = *reinterpret_cast<const ulonglong2 *>(line + 2);
+        const ulonglong2 x2 = *reinterpret_cast<const ulonglong2 *>(line + 4), x3 = *reinterpret_cast<const ulonglong2 *>(line + 6);
+        if (cnt) cnt[0] += 1;
+        const uint64_t sl[8] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y, x3.x, x3.y};
+        uint64_t e = 0;
+        int state = x0.x == ~0ull ? 3 : 2;                               // (an overflowed line is all ones)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (sl[i] != 0 && sl[i] != ~0ull && (uint32_t) (sl[i] >> 56) == tag) { e = sl[i]; state = 1; }
+        if (state != 3) {
+            if (state != 1) { k = 0; l = 0; return 0; }                  // dead by its 16th base
+            k = e & ((1ull << 40) - 1ull);
+            l = k + ((e >> 40) & 0xFFFFull) - 1;
+            left = left2;
+            looked_up = true;
+        }
+    }
+    if (!looked_up && ix.lcl && seed_len >= ix.hl) {
         // Long table: entry[hl-mer] = lc[hlen-mer] followed by hl - hlen backward steps, precomputed on the device
         // (lcl_build_kernel) -- the same (k, l) the reference reaches after those steps, for one memory request
         // instead of 1 + 2(hl - hlen).  The kernel is bound by the number of requests, and most seeds of a noisy
@@ -270,6 +306,41 @@ __global__ __launch_bounds__(256) void lclx_build_kernel(const uint64_t *__restr
     }
 }
 
+// Core table (see seed_one): every 16-mer X the text holds (a non-zero entry of the pair-line table `pl`) enters the lines
+// of its four cores, once per role.  A line that cannot take an entry (all eight slots taken, or a count beyond 16 bits)
+// goes on the overflow list and is set to all ones afterwards.
+__device__ __forceinline__ void core_insert(uint64_t *core, uint64_t corec, uint32_t tag, uint64_t entry, bool fits, uint64_t *ovf,
+                                            uint64_t ovf_cap, unsigned long long *n_ovf) {
+    uint64_t *line = core + corec * 8;
+    (void) tag;
+    if (fits)
+        for (int sl = 0; sl < 8; ++sl)                                     // slots fill from the front
+            if (atomicCAS((unsigned long long *) &line[sl], 0ull, (unsigned long long) entry) == 0ull) return;
+    const unsigned long long at = atomicAdd(n_ovf, 1ull);
+    if (at < ovf_cap) ovf[at] = corec;
+}
+__global__ __launch_bounds__(256) void core_build_kernel(const uint64_t *__restrict__ pl, uint64_t *__restrict__ core, uint64_t x0,
+                                                         uint64_t *__restrict__ ovf, uint64_t ovf_cap, unsigned long long *n_ovf) {
+    const uint64_t X = x0 + (uint64_t) blockIdx.x * 256 + threadIdx.x;                  // a 16-mer, first base lowest
+    if (X >> 32) return;
+    const uint64_t e = pl[((X >> 2) << 3) + (X & 3u)];                                  // its entry as the left extension of its last 15 bases
+    if (e == 0) return;
+    const uint64_t c = e >> 40;
+    const bool fits = c < 0xFFFFull;
+    const uint64_t body = (e & ((1ull << 40) - 1ull)) | ((c & 0xFFFFull) << 40);
+    for (uint32_t r = 0; r < 4; ++r) {
+        const uint64_t corec = (X >> (2 * (3 - r))) & ((1ull << 26) - 1ull);
+        const uint32_t extra = (uint32_t) (X & ((1ull << (2 * (3 - r))) - 1ull)) | ((uint32_t) (X >> (2 * (16 - r))) << (2 * (3 - r)));
+        const uint32_t tag = r | (extra << 2);
+        core_insert(core, corec, tag, body | ((uint64_t) tag << 56), fits, ovf, ovf_cap, n_ovf);
+    }
+}
+__global__ __launch_bounds__(256) void core_ovf_kernel(uint64_t *__restrict__ core, const uint64_t *__restrict__ ovf, uint64_t n) {
+    const uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * 8) return;
+    core[ovf[i >> 3] * 8 + (i & 7)] = ~0ull;
+}
+
 // The long seed table.  seed_search's time is its L2 misses divided by ~50 G random 64-byte lines per second
 // (tools/randline_bench.hip pins that rate independently), and the first lookup of a seed is a miss whatever the text,
 // so the table is (a) as long as HBM allows -- the longer the k-mer, the more noisy seeds die in the lookup instead of one
@@ -338,6 +409,32 @@ int lrm_lcl_prepare_index(lrm_index *idx) {
     idx->view.lcl_kbits = ebytes == 5 ? kbits : 0;
     idx->view.lclx = tab;
     idx->view.lclx_mask = mask;
+    // Core table on top of pair-line 16-mers with 8-byte entries, for texts small enough that a 13-mer's line holds the
+    // 16-mers around it (4 L / 4^13 entries per line on average: 0.55 for an E. coli-sized text, 2 at 2^25 rows).
+    const bool core_auto = L <= (1ull << 25);
+    if (hl == 16 && pair && ebytes == 8 && (tu.lc_core > 0 || (tu.lc_core < 0 && core_auto))) {
+        uint64_t *dc = nullptr, *covf = nullptr;
+        unsigned long long *cn = nullptr;
+        const uint64_t lines = 1ull << 26, ocap = 16ull << 20;
+        bool ok = hipMalloc(&dc, lines * 64) == hipSuccess && hipMalloc(&covf, ocap * 8) == hipSuccess && hipMalloc(&cn, 8) == hipSuccess &&
+                  hipMemset(dc, 0, lines * 64) == hipSuccess && hipMemset(cn, 0, 8) == hipSuccess;
+        if (ok) {
+            for (uint64_t b0 = 0, blocks = (1ull << 32) / 256; b0 < blocks; b0 += chunk) {
+                const uint64_t nb = blocks - b0 < chunk ? blocks - b0 : chunk;
+                hipLaunchKernelGGL(core_build_kernel, dim3((uint32_t) nb), dim3(256), 0, 0, (const uint64_t *) d, dc, b0 * 256, covf, ocap, cn);
+            }
+            unsigned long long n = 0;
+            ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(&n, cn, 8, hipMemcpyDeviceToHost) == hipSuccess && n <= ocap;
+            if (ok && n) {
+                hipLaunchKernelGGL(core_ovf_kernel, dim3((uint32_t) ((n * 8 + 255) / 256)), dim3(256), 0, 0, dc, (const uint64_t *) covf, (uint64_t) n);
+                ok = hipDeviceSynchronize() == hipSuccess;
+            }
+        }
+        if (covf) (void) hipFree(covf);
+        if (cn) (void) hipFree(cn);
+        if (ok) { idx->d_core = dc; idx->view.core = dc; }
+        else { if (dc) (void) hipFree(dc); (void) hipGetLastError(); }      // no room or too many crowded lines: the pair-line table alone
+    }
     return 0;
 }
 

@@ -121,7 +121,7 @@ def test_gact_rejects_unsupported_params(gpu):
         assert rc < 0 and b"unsupported GACT" in capi.lib.lrm_last_error()
 
 
-@pytest.mark.parametrize("long_table", ["0", "auto", "16", "13-plain", "14", "15-5byte", "14-5byte-side"])
+@pytest.mark.parametrize("long_table", ["0", "auto", "16-nocore", "16-core", "13-plain", "14", "15-5byte", "14-5byte-side"])
 @pytest.mark.parametrize("name", ["clean-1k", "ont-2k", "pacbio-3k-h12", "ragged", "seed12", "seed32",
                                   "seed-below-hlen", "repeats-ties"])
 def test_seed_search_per_seed(dev_indexes, gpu, name, long_table):
@@ -137,6 +137,7 @@ def test_seed_search_per_seed(dev_indexes, gpu, name, long_table):
     if long_table != "auto":
         own = di = index.DeviceIndex.upload(sc["hi"], gpu, lc_long=int(long_table.split("-")[0]),
                                             lc_pair=0 if long_table.endswith("-plain") else None,
+                                            lc_core=1 if long_table.endswith("-core") else 0,         # four positions per line
                                             lc_entry_bytes=5 if "5byte" in long_table else None,      # 40 bytes per (k-1)-mer
                                             lc_count_bits=2 if long_table.endswith("-side") else None)  # counts >= 3: side hash table
     s = sc["seed_len"]
@@ -176,7 +177,8 @@ def test_seed_batch_vs_oracle(dev_indexes, gpu, name):
     for f in ("key", "val", "bucket"):
         assert np.array_equal(got[f], want[f]), (name, f, np.nonzero(got[f] != want[f])[0][:10])
     # the same through the long seed table (what large texts use automatically)
-    for tag, opts in (("long table", dict(lc_long=14)), ("5-byte long table", dict(lc_long=15, lc_entry_bytes=5)),
+    for tag, opts in (("long table", dict(lc_long=14)), ("pair-line 16-mers without the core table", dict(lc_long=16, lc_core=0)),
+                      ("5-byte long table", dict(lc_long=15, lc_entry_bytes=5)),
                       ("5-byte long table, side hash table", dict(lc_long=14, lc_entry_bytes=5, lc_count_bits=2))):
         d2 = index.DeviceIndex.upload(sc["hi"], gpu, **opts)
         got = mapper.seed_batch(d2, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
