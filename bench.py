@@ -192,7 +192,12 @@ def main():
     blob = dist.broadcast_blob(blob, device=dev, src=0)
     torch.cuda.synchronize()
     t_bcast = time.time() - t1
-    di = index.DeviceIndex.adopt(blob, local)
+    t1 = time.time()
+    di = index.DeviceIndex.adopt(blob, local)          # derives the planar text and the seed tables on the device
+    di_tables = di.tables()
+    di_tables["derive_s"] = round(time.time() - t1, 2)
+    if rank == 0:
+        log("derived tables: %s" % di_tables)
 
     # ---- reads: every rank maps its own batch (weak scaling), resident in HBM ----------------------
     n, Lr = args.reads, args.read_len
@@ -593,7 +598,7 @@ def main():
                algorithmic_bytes_per_base=dict(reference_layout=per_base, device_layout=dev_per_base), stats=stats,
                index=dict(rows=hi.length, image_bytes=int(blob.numel()), reference_s=round(t_synth, 1), build_s=round(t_build, 1),
                           pack_upload_s=round(t_pack, 1), broadcast_s=round(t_bcast, 3),
-                          host_cpus=usable_cpus(), peak_rss_gb=round(peak_rss_gb(), 1)),
+                          host_cpus=usable_cpus(), peak_rss_gb=round(peak_rss_gb(), 1), tables=di_tables),
                speedup_vs_cpu=value / cpu["value"],
                speedup_pcie_inclusive_vs_cpu=(pcie["value"] / cpu["value"]) if pcie else None)
 

@@ -117,7 +117,17 @@ typedef struct lrm_index_options {
                                   (4 GiB): -1 automatic, 0 off, 1 on */
     uint32_t lc_count_bits;    /* tests: count bits of the 5-byte entries (0: 40 - ceil(log2(rows))); a small value sends
                                   ordinary repeats through the side hash table */
-    uint32_t reserved[7];
+    int32_t seed_table;        /* SEED table: a hash table of the text's seed_table_len-mers -- (first row, count) of every distinct one,
+                                  the exact result of lc_aln + fmi_aln (lchash.c:89-104, fmidx.c:295-313) for it -- in 64-byte lines
+                                  that the seeds of 4 (or 2) neighbouring read positions share: a seed of that length costs a quarter
+                                  (half) of a memory line and no backward step.  -1 automatic (pure ACGT texts, when HBM allows: 2 GiB
+                                  for an E. coli-sized text, 64 GiB chr1-sized, 128 GiB GRCh38-sized), 0 off, 1 on.  Seeds of any
+                                  other length go through the tables above. */
+    uint32_t seed_table_len;   /* seed length the table is built for: 0 = 20, the reference's default (alnmain.c:577-580); 16..24 */
+    uint32_t seed_table_share; /* read positions per line: 0 automatic, 4 (8-byte slots, eight per line) or 2 (6-byte slots, ten) */
+    uint32_t seed_table_bits;  /* tests: log2 of the number of lines (0: automatic) -- few lines force the overflow paths */
+    uint32_t seed_table_count_bits; /* tests: count bits of a slot (0: all that are left) -- few send repeats to the side table */
+    uint32_t reserved[2];
 } lrm_index_options;
 void lrm_index_options_init(lrm_index_options *o);
 
@@ -212,6 +222,25 @@ int lrm_index_upload_blob_opt(lrm_index **out, const void *blob, uint64_t blob_b
 /* Default options of the batch calls on this handle (every replica of a group): lrm_seed_batch, lrm_extend_batch,
  * lrm_map_batch and the *_dev calls use them; lrm_map_batch_submit takes its own.  NULL restores the automatic choices. */
 int lrm_index_set_map_options(lrm_index *idx, const lrm_map_options *opt);
+
+/* Which derived seed tables a handle (replica 0 of a group) ended up with -- the automatic choices depend on the text
+ * and on the HBM that was free at upload.  Results never depend on them. */
+typedef struct lrm_index_tables {
+    int32_t lc_long;             /* k-mer length of the long table (0: none) */
+    int32_t lc_pair;             /* pair-line layout */
+    int32_t lc_entry_bytes;      /* 8 or 5 */
+    int32_t lc_core;             /* core table present */
+    int32_t seed_table_len;      /* seed length of the seed table (0: none) */
+    int32_t seed_table_share;    /* read positions per line: 4 or 2 */
+    int32_t seed_table_bits;     /* log2 of its lines (64 bytes each) */
+    int32_t seed_table_slot_bytes;
+    int32_t seed_table_count_bits;
+    int32_t reserved0;
+    uint64_t seed_table_side_entries;   /* entries of crowded lines / counts beyond the slot's bits, in the side hash table */
+    uint64_t derived_bytes;      /* HBM held by all derived tables (long table, core table, seed table, side tables) */
+    uint64_t reserved[4];
+} lrm_index_tables;
+int lrm_index_get_tables(const lrm_index *idx, lrm_index_tables *out);
 
 /* Adopt a blob that already sits in device memory (e.g. the destination of an
  * RCCL broadcast).  The blob is borrowed: it must outlive the handle. */

@@ -61,7 +61,16 @@ class GactParams(C.Structure):
 class IndexOptions(C.Structure):       # lrm_index_options
     _fields_ = [("struct_size", C.c_uint32), ("sa_sampled", C.c_int32), ("lc_long", C.c_int32),
                 ("lc_long_max", C.c_int32), ("lc_pair", C.c_int32), ("lcx_threshold", C.c_uint32),
-                ("lc_entry_bytes", C.c_uint32), ("lc_core", C.c_int32), ("lc_count_bits", C.c_uint32), ("reserved", C.c_uint32 * 7)]
+                ("lc_entry_bytes", C.c_uint32), ("lc_core", C.c_int32), ("lc_count_bits", C.c_uint32),
+                ("seed_table", C.c_int32), ("seed_table_len", C.c_uint32), ("seed_table_share", C.c_uint32),
+                ("seed_table_bits", C.c_uint32), ("seed_table_count_bits", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+
+
+class IndexTables(C.Structure):        # lrm_index_tables
+    _fields_ = [("lc_long", C.c_int32), ("lc_pair", C.c_int32), ("lc_entry_bytes", C.c_int32), ("lc_core", C.c_int32),
+                ("seed_table_len", C.c_int32), ("seed_table_share", C.c_int32), ("seed_table_bits", C.c_int32),
+                ("seed_table_slot_bytes", C.c_int32), ("seed_table_count_bits", C.c_int32), ("reserved0", C.c_int32),
+                ("seed_table_side_entries", C.c_uint64), ("derived_bytes", C.c_uint64), ("reserved", C.c_uint64 * 4)]
 
 
 class MapOptions(C.Structure):         # lrm_map_options
@@ -119,6 +128,7 @@ SYMBOLS = {
     "lrm_index_upload_blob_opt": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_int,
                                             C.POINTER(IndexOptions)]),
     "lrm_index_set_map_options": (C.c_int, [C.c_void_p, C.POINTER(MapOptions)]),
+    "lrm_index_get_tables": (C.c_int, [C.c_void_p, C.POINTER(IndexTables)]),
     "lrm_map_batch_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, Params, GactParams,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.POINTER(MapOptions), C.POINTER(C.c_void_p)]),

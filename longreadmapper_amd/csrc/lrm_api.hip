@@ -68,7 +68,7 @@ static inline uint64_t align256(uint64_t x) { return (x + 255ull) & ~255ull; }
 // options: the caller's structs, then the LRM_* environment overrides as they stood when the handle was created
 // ------------------------------------------------------------------------------------------
 static const char *const k_env_names[] = {
-    "LRM_SA_SAMPLED", "LRM_LC_LONG", "LRM_LC_PAIR", "LRM_LC_BYTES", "LRM_LC_CORE", "LRM_LCX_THRESHOLD",                        // index
+    "LRM_SA_SAMPLED", "LRM_LC_LONG", "LRM_LC_PAIR", "LRM_LC_BYTES", "LRM_LC_CORE", "LRM_LCX_THRESHOLD", "LRM_SD", "LRM_SD_SHARE", "LRM_SD_BITS",   // index
     "LRM_GACT_IMPL", "LRM_SEED_ROUNDS", "LRM_HOST_DENSE", "LRM_HOST_SLICE", "LRM_HOST_SUBS",
     "LRM_HOST_GROUP", "LRM_BS_WAVES", "LRM_SS_ITEMS", "LRM_VOTE_VG", "LRM_VOTE_T1", "LRM_VOTE_U", "LRM_VOTE_LOAD",
     "LRM_HOST_EXT_STREAMS", "LRM_HOST_SEED_STREAMS", "LRM_HOST_VERBOSE", "LRM_VOTE_FAST", "LRM_HOST_SLOTS", "LRM_SS_PAD"};
@@ -95,6 +95,7 @@ extern "C" void lrm_index_options_init(lrm_index_options *o) {
     o->lc_long = -1;
     o->lc_pair = -1;
     o->lc_core = -1;
+    o->seed_table = -1;
 }
 extern "C" void lrm_map_options_init(lrm_map_options *o) {
     if (!o) return;
@@ -116,6 +117,11 @@ void lrm_resolve_index_tune(const lrm_index_options *opt, const LrmEnv &env, Lrm
     t->lc_entry_bytes = o.lc_entry_bytes == 5 || o.lc_entry_bytes == 8 ? (int) o.lc_entry_bytes : 0;
     t->lc_count_bits = o.lc_count_bits >= 2 && o.lc_count_bits <= 24 ? (int) o.lc_count_bits : 0;
     t->lc_core = o.lc_core;
+    t->sd = o.seed_table;
+    t->sd_len = o.seed_table_len >= 16 && o.seed_table_len <= 24 ? (int) o.seed_table_len : 20;        // alnmain.c:577-580: seed_len 20
+    t->sd_f = o.seed_table_share == 2 || o.seed_table_share == 4 ? (int) o.seed_table_share : 0;
+    t->sd_bits = o.seed_table_bits >= 4 && o.seed_table_bits <= 32 ? (int) o.seed_table_bits : 0;
+    t->sd_cbits = o.seed_table_count_bits >= 2 && o.seed_table_count_bits <= 24 ? (int) o.seed_table_count_bits : 0;
     t->lcx_threshold = o.lcx_threshold >= 1 && o.lcx_threshold <= 0xFFFFFFu ? o.lcx_threshold : 0xFFFFFFull;
     long long v;
     if (env.get("LRM_SA_SAMPLED", &v)) t->sa_ratio = valid_sa_ratio(v) ? (int) v : 1;
@@ -123,6 +129,9 @@ void lrm_resolve_index_tune(const lrm_index_options *opt, const LrmEnv &env, Lrm
     if (env.get("LRM_LC_PAIR", &v)) t->lc_pair = v != 0;
     if (env.get("LRM_LC_BYTES", &v) && (v == 5 || v == 8)) t->lc_entry_bytes = (int) v;
     if (env.get("LRM_LC_CORE", &v)) t->lc_core = v != 0;
+    if (env.get("LRM_SD", &v)) t->sd = v != 0;
+    if (env.get("LRM_SD_SHARE", &v) && (v == 2 || v == 4)) t->sd_f = (int) v;
+    if (env.get("LRM_SD_BITS", &v) && v >= 4 && v <= 32) t->sd_bits = (int) v;
     if (env.get("LRM_LCX_THRESHOLD", &v) && v >= 1 && v <= 0xFFFFFFll) t->lcx_threshold = (uint64_t) v;
 }
 
@@ -493,6 +502,8 @@ static int make_handle(lrm_index **out, void *d_blob, uint64_t bytes, int device
     for (int i = 0; i < 4; ++i) ix->view.c4[i] = h.c4[i];
     ix->view.hlen = h.hlen; ix->view.mta_len = h.mta_len;
     ix->view.core = nullptr;
+    ix->view.sd = nullptr; ix->view.sdx = nullptr; ix->view.sdx_mask = 0;
+    ix->view.sd_len = ix->view.sd_f = ix->view.sd_bits = ix->view.sd_kbits = ix->view.sd_slot = ix->view.sd_cbits = 0;
     ix->view.lcl = nullptr; ix->view.hl = 0; ix->view.lcl_pair = 0; ix->view.lcl_kbits = 0; ix->view.lclx = nullptr; ix->view.lclx_mask = 0;
     ix->view.sa_shift = 0;
     for (uint64_t r = h.sa_ratio > 1 ? h.sa_ratio : 1; r > 1; r >>= 1) ix->view.sa_shift++;
@@ -788,6 +799,27 @@ extern "C" int lrm_debug_set_vote_limits(lrm_index *idx, uint32_t t3_limit, uint
     return 0;
 }
 
+extern "C" int lrm_index_get_tables(const lrm_index *idx, lrm_index_tables *out) {
+    if (!idx || !out) { lrm_set_error("lrm_index_get_tables: null argument"); return -1; }
+    memset(out, 0, sizeof(*out));
+    const LrmIndexView &v = idx->view;
+    uint64_t bytes = 0;
+    if (v.lcl) {
+        out->lc_long = v.hl; out->lc_pair = v.lcl_pair; out->lc_entry_bytes = v.lcl_kbits ? 5 : 8;
+        bytes += ((v.lcl_pair ? 2ull : 1ull) << (2 * v.hl)) * (uint64_t) out->lc_entry_bytes;
+        if (v.lclx) bytes += (v.lclx_mask + 1) * 16;
+    }
+    if (v.core) { out->lc_core = 1; bytes += 64ull << 26; }
+    if (v.sd) {
+        out->seed_table_len = v.sd_len; out->seed_table_share = v.sd_f; out->seed_table_bits = v.sd_bits;
+        out->seed_table_slot_bytes = v.sd_slot; out->seed_table_count_bits = v.sd_cbits;
+        out->seed_table_side_entries = idx->sd_side_entries;
+        bytes += (64ull << v.sd_bits) + (v.sdx_mask + 1) * 16;
+    }
+    out->derived_bytes = bytes;
+    return 0;
+}
+
 extern "C" int lrm_index_replicas(const lrm_index *idx) { return idx ? idx->n_peers : 0; }
 extern "C" lrm_index *lrm_index_replica(lrm_index *idx, int r) {
     if (!idx || r < 0 || r >= idx->n_peers) return nullptr;
@@ -807,6 +839,8 @@ extern "C" void lrm_index_free(lrm_index *idx) {
     if (idx->d_lcl) (void) hipFree(idx->d_lcl);
     if (idx->d_lclx) (void) hipFree(idx->d_lclx);
     if (idx->d_core) (void) hipFree(idx->d_core);
+    if (idx->d_sd) (void) hipFree(idx->d_sd);
+    if (idx->d_sdx) (void) hipFree(idx->d_sdx);
     if (idx->owns_blob && idx->d_blob) (void) hipFree(idx->d_blob);
     delete idx;
 }

@@ -81,6 +81,17 @@ struct LrmIndexView {
                               // the 16-mers around it, so that the lookups of FOUR neighbouring read positions share a line; null = unused
     const uint64_t *lclx;     // side hash table of the 5-byte layout: {hl-mer code + 1, k | count << 40} pairs, open addressing
     uint64_t lclx_mask;       // slots - 1 (a power of two)
+    // optional SEED table (seed_kernels.hip): (first row, count) of every distinct sd_len-mer of the text in 64-byte lines shared
+    // by the seeds of sd_f neighbouring read positions; null = unused
+    const uint64_t *sd;
+    const uint64_t *sdx;      // its side hash table {code + 1, k | count << 40}: entries of crowded lines, counts beyond the slot's bits
+    uint64_t sdx_mask;
+    int32_t sd_len;           // seed length it holds
+    int32_t sd_f;             // read positions per line: 4 or 2
+    int32_t sd_bits;          // log2 lines
+    int32_t sd_kbits;         // bits of k in a slot
+    int32_t sd_slot;          // slot bytes: 8 (eight per line, overflow flag in slot 0) or 6 (ten per line, entry count in the last 4 bytes)
+    int32_t sd_cbits;         // count bits of a slot (all ones: the side table has the count)
 };
 
 // ---- resolved choices of a handle ------------------------------------------------------------------------------
@@ -97,6 +108,7 @@ void lrm_env_snapshot(LrmEnv *e);
 struct LrmIndexTune {
     int sa_ratio;                   // 1: full SA; 2..64: sampled
     int lc_long, lc_long_max, lc_pair, lc_entry_bytes, lc_count_bits, lc_core;
+    int sd, sd_len, sd_f, sd_bits, sd_cbits;      // seed table: -1 / 0 / 1, seed length, positions per line (0 automatic), tests: lines, count bits
     uint64_t lcx_threshold;
 };
 struct LrmMapTune {
@@ -120,6 +132,8 @@ struct lrm_index {
     uint64_t *d_lcl;          // long lc table (owned; may be null)
     uint64_t *d_lclx;         // its side hash table in the 5-byte layout (owned; may be null)
     uint64_t *d_core;         // core table (owned; may be null)
+    uint64_t *d_sd, *d_sdx;   // seed table and its side hash table (owned; may be null)
+    uint64_t sd_side_entries; // entries of the side table (stats)
     uint64_t *d_cpl;          // planar 2-bit copy of the text for the bit-sliced GACT kernel (owned; may be null)
     int cpl_ok;               // text is pure ACGT (otherwise the byte kernels are used)
     uint64_t *d_sas;          // sampled-SA locate mode (csa_access, fmidx.c:315-331): SA rows i*sa_ratio (owned; may be null)

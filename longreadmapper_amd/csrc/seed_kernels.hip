@@ -15,6 +15,7 @@
 // clean reads the host launches phase 0 first and phases 1..s only for undecided reads.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstdio>
 #include "lrm_internal.h"
 
 
@@ -120,6 +121,95 @@ __device__ __forceinline__ void lc_lookup(const LrmIndexView &ix, uint64_t code,
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// SEED table: the whole of lc_aln + fmi_aln for a seed of sd_len bases in ONE memory line that the seeds of sd_f
+// neighbouring read positions share.
+//   The seeds at read positions p0 .. p0 + F - 1 (p0 a multiple of F = sd_f) share the CORE [p0 + F - 1, p0 + S): S - F + 1
+//   bases.  A bijective hash of the core gives the line (its top sd_bits bits) and a residue (the rest); a slot of the line
+//   is { k, count, tag } with tag = the seed's role r = p - p0, its F - 1 bases outside the core and the residue -- so a tag
+//   names one S-mer exactly, and a lookup that finds no slot with its tag has proved the S-mer absent from the text
+//   (rr = 0), which is how most seeds of a noisy read end.  Every distinct S-mer of the text is entered once per role with
+//   the (k, l - k + 1) a real search gave for it (sd_build_kernel), so the table IS the reference's result, also where the
+//   reference has a quirk (the '$' row).
+//   8-byte slots (eight per line): k in the low sd_kbits bits, the count above, bit 63 - tagbits of slot 0 = "line
+//   overflowed", the tag in the top bits.  6-byte slots (ten per line, texts of >= 2^32 rows): k | count << kbits | tag
+//   << (48 - tagbits), the last four bytes of the line count its entries (> 10: overflowed).
+//   Entries that found no room, and counts of all ones, are in a side hash table keyed by the S-mer.
+// ----------------------------------------------------------------------------------------
+#define LRM_SD_MULT 0x9E3779B97F4A7C15ull
+struct SdKey { uint64_t line; uint64_t tag; uint32_t tb; };
+__device__ __forceinline__ SdKey sd_key_of(const LrmIndexView &ix, uint64_t code, uint32_t r) {
+    const uint32_t lf = ix.sd_f == 4 ? 2u : 1u, F = 1u << lf, lo_n = F - 1u - r;
+    const uint32_t CL2 = 2u * ((uint32_t) ix.sd_len - F + 1u);
+    const uint64_t core = (code >> (2u * lo_n)) & ((1ull << CL2) - 1ull);
+    const uint64_t extra = (code & ((1ull << (2u * lo_n)) - 1ull)) | ((code >> (2u * lo_n + CL2)) << (2u * lo_n));
+    const uint64_t h = (core * LRM_SD_MULT) & ((1ull << CL2) - 1ull);            // odd multiplier: a bijection of the core
+    const uint32_t rb = CL2 - (uint32_t) ix.sd_bits;
+    SdKey key;
+    key.line = h >> rb;
+    key.tb = lf + 2u * (F - 1u) + rb;
+    key.tag = (uint64_t) r | (extra << lf) | ((h & ((1ull << rb) - 1ull)) << (lf + 2u * (F - 1u)));
+    return key;
+}
+// side table: true + entry (k | count << 40) when the S-mer is there
+__device__ __forceinline__ bool sd_side_lookup(const LrmIndexView &ix, uint64_t code, uint64_t &e) {
+    uint64_t slot = (code * 0x9E3779B97F4A7C15ull) >> 20 & ix.sdx_mask;
+    for (;;) {
+        const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(ix.sdx + 2 * slot);
+        if (x.x == code + 1) { e = x.y; return true; }
+        if (x.x == 0) return false;
+        slot = (slot + 1) & ix.sdx_mask;
+    }
+}
+// 0: absent (rr = 0); 1: k, c set; 2: take the other tables (a count beyond 24 bits)
+__device__ __forceinline__ int sd_lookup(const LrmIndexView &ix, uint64_t win, uint32_t jpar, uint64_t &k, uint64_t &c, uint32_t *cnt) {
+    const uint64_t code = win & ((1ull << (2 * ix.sd_len)) - 1ull);
+    const SdKey key = sd_key_of(ix, code, jpar & (uint32_t) (ix.sd_f - 1));
+    const uint64_t *line = ix.sd + key.line * 8;
+    // the whole line in ONE round trip (four independent 16-byte requests), searched in registers
+    const ulonglong2 x0 = *reinterpret_cast<const ulonglong2 *>(line), x1 = *reinterpret_cast<const ulonglong2 *>(line + 2);
+    const ulonglong2 x2 = *reinterpret_cast<const ulonglong2 *>(line + 4), x3 = *reinterpret_cast<const ulonglong2 *>(line + 6);
+    if (cnt) cnt[0] += 1;
+    const uint64_t W[8] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y, x3.x, x3.y};
+    uint64_t e = 0;
+    bool ovf;
+    uint32_t sbits;
+    if (ix.sd_slot == 8) {
+        sbits = 64;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (W[i] != 0 && (W[i] >> (64u - key.tb)) == key.tag) e = W[i];
+        ovf = (W[0] >> (63u - key.tb)) & 1ull;
+    } else {
+        sbits = 48;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int w = (48 * i) >> 6, off = (48 * i) & 63;
+            uint64_t v = W[w] >> off;
+            if (off > 16) v |= W[w + 1] << (64 - off);
+            v &= (1ull << 48) - 1ull;
+            if (v != 0 && (v >> (48u - key.tb)) == key.tag) e = v;
+        }
+        ovf = (uint32_t) (W[7] >> 32) > 10u;
+    }
+    const uint64_t cmax = (1ull << ix.sd_cbits) - 1ull;
+    if (e != 0) {
+        k = e & ((1ull << ix.sd_kbits) - 1ull);
+        c = (e >> ix.sd_kbits) & cmax;
+        if (c != cmax) return 1;
+    } else if (!ovf) {
+        return 0;
+    }
+    (void) sbits;
+    uint64_t se;
+    if (cnt) cnt[0] += 2;
+    if (!sd_side_lookup(ix, code, se)) return e != 0 ? 2 : 0;           // (a saturated count without a side entry: never)
+    if ((se >> 40) == 0xFFFFFFull) return 2;
+    k = se & ((1ull << 40) - 1ull);
+    c = se >> 40;
+    return 1;
+}
+
 // lc_aln (lchash.c:89-104) + fmi_aln (fmidx.c:295-313) on the packed read.
 // win: bases j.. of the read, 2 bits each, LSB first.  Returns rr; k,l as the reference
 // leaves them (also on failure).
@@ -129,6 +219,12 @@ __device__ __forceinline__ uint64_t seed_one(const LrmIndexView &ix, uint64_t wi
                                              uint64_t &k, uint64_t &l, uint32_t *cnt = nullptr) {
     int left = seed_len - ix.hlen;
     bool looked_up = false;
+    if (ix.sd && seed_len == ix.sd_len) {
+        uint64_t c;
+        const int st = sd_lookup(ix, win, jpar, k, c, cnt);
+        if (st == 0) { k = 0; l = 0; return 0; }                          // the text does not hold this seed
+        if (st == 1) { l = k + c - 1; return c; }
+    }
     if (ix.core && seed_len >= 16) {
         // CORE table (small texts): the 16-mers of read positions p0 .. p0 + 3 (p0 a multiple of 4) share the 13 bases
         // [p0 + 3, p0 + 16) of their windows; the line of that 13-mer holds the entries of the text's 16-mers around it
@@ -341,6 +437,149 @@ __global__ __launch_bounds__(256) void core_ovf_kernel(uint64_t *__restrict__ co
     core[ovf[i >> 3] * 8 + (i & 7)] = ~0ull;
 }
 
+// Seed table build, one lane per text position p: the S-mer at p is searched as a seed would be (through whatever
+// tables the handle already has); the first lane to claim the interval's first row k in a bitmap over the rows (distinct
+// S-mers have disjoint intervals) enters it -- once per distinct S-mer -- into the lines of its F roles.  What does not
+// fit (a full line, a count of cmax or more) goes on the list for the side hash table.  Only the text and the FM index
+// are read, never the suffix array.
+__global__ __launch_bounds__(256) void sd_build_kernel(LrmIndexView ix, LrmIndexView sdv, uint64_t *__restrict__ sd, uint64_t p0,
+                                                       uint32_t *__restrict__ claimed,
+                                                       uint64_t *__restrict__ ovf, uint64_t ovf_cap, unsigned long long *__restrict__ n_ovf) {
+    const uint64_t p = p0 + (uint64_t) blockIdx.x * 256 + threadIdx.x;
+    const int S = sdv.sd_len;
+    if (ix.con_len < (uint64_t) S + 1 || p > ix.con_len - 1 - (uint64_t) S) return;          // content[con_len - 1] is the '$'
+    uint64_t code = 0;
+    for (int i = 0; i < S; ++i) code |= (uint64_t) base_code((uint8_t) ix.content[p + i]) << (2 * i);
+    uint64_t k, l;
+    const uint64_t rr = seed_one(ix, code, S, (uint32_t) p, k, l);                            // (ix.sd is null here)
+    if (rr == 0) return;
+    if (atomicOr(&claimed[k >> 5], 1u << (k & 31u)) & (1u << (k & 31u))) return;               // another occurrence entered this S-mer
+    const uint64_t cmax = (1ull << sdv.sd_cbits) - 1ull;
+    const uint64_t c = rr < cmax ? rr : cmax;
+    const uint64_t side = k | ((rr < 0xFFFFFFull ? rr : 0xFFFFFFull) << 40);
+    bool to_side = rr >= cmax;
+    for (uint32_t r = 0; r < (uint32_t) sdv.sd_f; ++r) {
+        const SdKey key = sd_key_of(sdv, code, r);
+        uint64_t *line = sd + key.line * 8;
+        bool placed = false;
+        if (sdv.sd_slot == 8) {
+            const uint64_t v = k | (c << sdv.sd_kbits) | (key.tag << (64u - key.tb));
+            for (int sl = 0; sl < 8 && !placed; ++sl)
+                placed = atomicCAS((unsigned long long *) &line[sl], 0ull, (unsigned long long) v) == 0ull;
+            if (!placed) atomicOr((unsigned long long *) &line[0], 1ull << (63u - key.tb));
+        } else {
+            const uint64_t v = k | (c << sdv.sd_kbits) | (key.tag << (48u - key.tb));
+            const uint32_t at = atomicAdd(reinterpret_cast<uint32_t *>(line) + 15, 1u);
+            if (at < 10u) {
+                uint16_t *h = reinterpret_cast<uint16_t *>(line) + 3 * at;                   // three 2-byte stores: slots are 6 bytes apart
+                h[0] = (uint16_t) v; h[1] = (uint16_t) (v >> 16); h[2] = (uint16_t) (v >> 32);
+                placed = true;
+            }
+        }
+        if (!placed) to_side = true;
+    }
+    if (to_side) {
+        const unsigned long long at = atomicAdd(n_ovf, 1ull);
+        if (at < ovf_cap) { ovf[2 * at] = code; ovf[2 * at + 1] = side; }
+    }
+}
+
+__global__ __launch_bounds__(256) void sd_clear_kernel(ulonglong2 *__restrict__ p, uint64_t n16) {
+    for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t) gridDim.x * 256) p[i] = make_ulonglong2(0, 0);
+}
+
+// Geometry and build of the seed table (see sd_lookup).  Lines: the smallest power of two that keeps the average line
+// at <= 2.2 entries of 8 (four positions per line: 4 entries per distinct S-mer) or, where that does not fit, at <= 6 of
+// 10 (two positions per line, 6-byte slots) -- an E. coli-sized text: 2 GiB; chr1-sized: 64 GiB; GRCh38-sized (6.2 G
+// rows): 128 GiB, 3.5 % of the lines overflow into a side table of ~0.13 G entries.
+struct SdPlan { int f, bits, slot, kbits, cbits; uint64_t bytes; };
+static bool sd_plan(const lrm_index *idx, uint64_t free_b, SdPlan *pl) {
+    const LrmIndexTune &tu = idx->itune;
+    const uint64_t L = idx->view.length;
+    const int S = tu.sd_len;
+    if (tu.sd == 0 || !idx->cpl_ok || L < 64 || idx->view.con_len != L) return false;
+    int kbits = 1;
+    while ((1ull << kbits) < L) ++kbits;
+    for (int f = 4; f >= 2; f -= 2) {
+        if (tu.sd_f && tu.sd_f != f) continue;
+        const int slot = f == 4 ? 8 : 6, lf = f == 4 ? 2 : 1, per_line = f == 4 ? 8 : 10;
+        const double target = f == 4 ? 2.2 : 6.0;
+        int bits = 10;
+        while ((double) f * (double) L / (double) (1ull << bits) > target && bits < 34) ++bits;
+        if (tu.sd_bits) bits = tu.sd_bits;
+        const int CL2 = 2 * (S - f + 1);
+        if (bits > CL2) bits = CL2;
+        const int tb = lf + 2 * (f - 1) + (CL2 - bits);
+        int cbits = (slot == 8 ? 63 : 48) - tb - kbits;
+        if (cbits < (tu.sd_bits ? 2 : 4) || tb > 40) continue;                  // (tests force few lines: long tags)
+        if (cbits > 24) cbits = 24;
+        if (tu.sd_cbits && tu.sd_cbits < cbits) cbits = tu.sd_cbits;
+        const uint64_t bytes = 64ull << bits;
+        (void) per_line;
+        // room: the table, its side table (<= 1/8 of it) and what the batch workspaces need afterwards
+        const uint64_t spare = bytes >= (32ull << 30) ? (40ull << 30) : (8ull << 30);
+        if (tu.sd < 0 && ((uint64_t) free_b < bytes + bytes / 8 + spare || (tu.lc_long_max >= 13 && bytes > (16ull << 30)))) continue;
+        pl->f = f; pl->bits = bits; pl->slot = slot; pl->kbits = kbits; pl->cbits = cbits; pl->bytes = bytes;
+        return true;
+    }
+    return false;
+}
+static int sd_build(lrm_index *idx, const SdPlan &pl) {
+    uint64_t *d = nullptr, *ovf = nullptr, *tab = nullptr;
+    uint32_t *claimed = nullptr;
+    unsigned long long *n_ovf = nullptr;
+    const char *why = "";
+    unsigned long long n = 0;
+    auto give_up = [&]() {
+        if (idx->mtune.verbose) fprintf(stderr, "[lrm] seed table (share %d, 2^%d lines, %d-byte slots) not built: %s (side entries %llu)\n", pl.f, pl.bits, pl.slot, why, n);
+        if (d) (void) hipFree(d); if (ovf) (void) hipFree(ovf); if (tab) (void) hipFree(tab); if (n_ovf) (void) hipFree(n_ovf);
+        if (claimed) (void) hipFree(claimed);
+        (void) hipGetLastError(); return 0; };
+    const uint64_t L = idx->view.length, lines = 1ull << pl.bits;
+    // (a core that occurs once in the text brings one entry PER ROLE to its line, so a line holds F x Poisson entries: with two
+    //  positions per line and 2.9 cores per line on average 7 % of the lines of a GRCh38-sized text need more than ten slots)
+    uint64_t ovf_cap = lines / 4 + 4096;
+    if (ovf_cap > (1ull << 30)) ovf_cap = 1ull << 30;
+    if (idx->itune.sd_bits) ovf_cap = (uint64_t) pl.f * L + 4096;                 // (tests force crowded lines)
+    why = "no room for the table";
+    if (hipMalloc(&d, pl.bytes) != hipSuccess) { d = nullptr; return give_up(); }
+    why = "no room for the overflow list";
+    if (hipMalloc(&ovf, ovf_cap * 16) != hipSuccess) { ovf = nullptr; return give_up(); }
+    if (hipMalloc(&n_ovf, 8) != hipSuccess) { n_ovf = nullptr; return give_up(); }
+    const uint64_t cl_bytes = ((L + 31) / 32 + 1) * 4;
+    if (hipMalloc(&claimed, cl_bytes) != hipSuccess) { claimed = nullptr; return give_up(); }
+    why = "memset failed";
+    if (hipMemset(claimed, 0, cl_bytes) != hipSuccess) return give_up();
+    hipLaunchKernelGGL(sd_clear_kernel, dim3(256 * 64), dim3(256), 0, 0, reinterpret_cast<ulonglong2 *>(d), pl.bytes / 16);     // (128 GiB: not a hipMemset)
+    if (hipGetLastError() != hipSuccess || hipMemset(n_ovf, 0, 8) != hipSuccess) return give_up();
+    LrmIndexView sdv = idx->view;
+    sdv.sd_len = idx->itune.sd_len; sdv.sd_f = pl.f; sdv.sd_bits = pl.bits; sdv.sd_kbits = pl.kbits; sdv.sd_slot = pl.slot; sdv.sd_cbits = pl.cbits;
+    const uint64_t chunk = 1ull << 22;
+    for (uint64_t b0 = 0, blocks = (L + 255) / 256; b0 < blocks; b0 += chunk) {
+        const uint64_t nb = blocks - b0 < chunk ? blocks - b0 : chunk;
+        hipLaunchKernelGGL(sd_build_kernel, dim3((uint32_t) nb), dim3(256), 0, 0, idx->view, sdv, d, b0 * 256, claimed, ovf, ovf_cap, n_ovf);
+    }
+    why = "build kernel failed";
+    if (hipDeviceSynchronize() != hipSuccess) { give_up(); lrm_set_error("seed table build failed"); return -1; }
+    why = "too many entries beside their lines";
+    if (hipMemcpy(&n, n_ovf, 8, hipMemcpyDeviceToHost) != hipSuccess || n > ovf_cap) return give_up();       // too crowded: the other tables alone
+    uint64_t tslots = 1024;
+    while (tslots < 2 * n) tslots <<= 1;
+    why = "no room for the side table";
+    if (hipMalloc(&tab, tslots * 16) != hipSuccess) { tab = nullptr; return give_up(); }
+    if (hipMemset(tab, 0, tslots * 16) != hipSuccess) return give_up();
+    if (n) hipLaunchKernelGGL(lclx_build_kernel, dim3((uint32_t) ((n + 255) / 256)), dim3(256), 0, 0, ovf, (uint64_t) n, tab, tslots - 1);
+    if (hipDeviceSynchronize() != hipSuccess) { give_up(); lrm_set_error("seed table side build failed"); return -1; }
+    (void) hipFree(ovf); (void) hipFree(n_ovf); (void) hipFree(claimed);
+    idx->d_sd = d; idx->d_sdx = tab;
+    idx->view.sd = d; idx->view.sdx = tab; idx->view.sdx_mask = tslots - 1;
+    idx->view.sd_len = sdv.sd_len; idx->view.sd_f = pl.f; idx->view.sd_bits = pl.bits; idx->view.sd_kbits = pl.kbits; idx->view.sd_slot = pl.slot;
+    idx->view.sd_cbits = pl.cbits;
+    idx->sd_side_entries = n;
+    if (idx->mtune.verbose) fprintf(stderr, "[lrm] seed table: %d positions per line, 2^%d lines, %d-byte slots, %d count bits, %llu side entries\n", pl.f, pl.bits, pl.slot, pl.cbits, n);
+    return 0;
+}
+
 // The long seed table.  seed_search's time is its L2 misses divided by ~50 G random 64-byte lines per second
 // (tools/randline_bench.hip pins that rate independently), and the first lookup of a seed is a miss whatever the text,
 // so the table is (a) as long as HBM allows -- the longer the k-mer, the more noisy seeds die in the lookup instead of one
@@ -356,17 +595,29 @@ __global__ __launch_bounds__(256) void core_ovf_kernel(uint64_t *__restrict__ co
 // table 0.65 s (2 s when the memory was freed a moment ago) -- repaid after a few hundred Gbp of reads, so callers that
 // know their run is short cap the length (lrm_index_options.lc_long_max; lrm_accaln does it from the size of the reads
 // file).
+static int lcl_prepare_tables(lrm_index *idx, size_t free_b, bool have_sd);
 int lrm_lcl_prepare_index(lrm_index *idx) {
-    const uint64_t L = idx->view.length;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); free_b = 0; }
+    // The seed table (seeds of the usual length) is planned first and built last, through the tables made here for the seeds
+    // of any other length; those make do with the HBM it leaves.
+    SdPlan sdp;
+    const bool want_sd = sd_plan(idx, free_b, &sdp);
+    if (want_sd) { const uint64_t need = sdp.bytes + sdp.bytes / 8; free_b = free_b > need ? free_b - need : 0; }
+    const int rc_lcl = lcl_prepare_tables(idx, free_b, want_sd);
+    if (rc_lcl) return rc_lcl;
+    return want_sd ? sd_build(idx, sdp) : 0;
+}
+
+static int lcl_prepare_tables(lrm_index *idx, size_t free_b, bool have_sd) {
+    const uint64_t L = idx->view.length;
     int hl = 13, pair = 1, ebytes = 8;
     int kbits = 1;
     while ((1ull << kbits) < L) ++kbits;
     static const struct { int hl, ebytes; uint64_t spare, min_rows; } ladder[] = {
         {17, 5, 40ull << 30, 1ull << 32}, {16, 8, 64ull << 30, 0}, {15, 8, 32ull << 30, 0}, {14, 8, 8ull << 30, 0}};
     for (const auto &c : ladder)
-        if (L >= c.min_rows && kbits <= 36 && (uint64_t) free_b >= (2ull * c.ebytes << (2 * c.hl)) + c.spare) { hl = c.hl; ebytes = c.ebytes; break; }
+        if (L >= c.min_rows && kbits <= 36 && !(have_sd && c.hl > 16) && (uint64_t) free_b >= (2ull * c.ebytes << (2 * c.hl)) + c.spare) { hl = c.hl; ebytes = c.ebytes; break; }
     const LrmIndexTune &tu = idx->itune;
     if (tu.lc_long_max >= 13 && hl > tu.lc_long_max) { hl = tu.lc_long_max; ebytes = 8; }      // the caller expects a short run
     if (tu.lc_long >= 0) { if (tu.lc_long != hl) ebytes = 8; hl = tu.lc_long; }

@@ -166,6 +166,12 @@ class DeviceIndex:
         """Default lrm_map_options of the batch calls on this handle (no arguments: the automatic choices)."""
         check(lib.lrm_index_set_map_options(self.handle, C.byref(capi.map_options(**opts))), "lrm_index_set_map_options")
 
+    def tables(self):
+        """The derived seed tables this handle ended up with (lrm_index_get_tables) as a dict."""
+        t = capi.IndexTables()
+        check(lib.lrm_index_get_tables(self.handle, C.byref(t)), "lrm_index_get_tables")
+        return {f: int(getattr(t, f)) for f, _ in t._fields_ if not f.startswith("reserved")}
+
     def debug_set_vote_limits(self, t3_limit=0, t3_slots=0):
         check(lib.lrm_debug_set_vote_limits(self.handle, t3_limit, t3_slots), "lrm_debug_set_vote_limits")
 

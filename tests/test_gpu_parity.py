@@ -121,7 +121,12 @@ def test_gact_rejects_unsupported_params(gpu):
         assert rc < 0 and b"unsupported GACT" in capi.lib.lrm_last_error()
 
 
-@pytest.mark.parametrize("long_table", ["0", "auto", "16-nocore", "16-core", "13-plain", "14", "15-5byte", "14-5byte-side"])
+def s_len_of(sc):
+    return sc["seed_len"]
+
+
+@pytest.mark.parametrize("long_table", ["0", "auto", "16-nocore", "16-core", "13-plain", "14", "15-5byte", "14-5byte-side",
+                                        "sd", "sd-share2", "sd-crowded", "sd-share2-crowded-counts"])
 @pytest.mark.parametrize("name", ["clean-1k", "ont-2k", "pacbio-3k-h12", "ragged", "seed12", "seed32",
                                   "seed-below-hlen", "repeats-ties"])
 def test_seed_search_per_seed(dev_indexes, gpu, name, long_table):
@@ -134,8 +139,21 @@ def test_seed_search_per_seed(dev_indexes, gpu, name, long_table):
         pytest.skip("explicit table variants are built for three scenarios only")
     sc, di, oi = dev_indexes(name)
     own = None
-    if long_table != "auto":
-        own = di = index.DeviceIndex.upload(sc["hi"], gpu, lc_long=int(long_table.split("-")[0]),
+    if long_table.startswith("sd"):
+        # the SEED table: (k, count) of every distinct 20-mer of the text, four (or two) read positions per 64-byte line;
+        # "crowded": so few lines that most entries live in the side hash table; "counts": 2 count bits per slot
+        own = di = index.DeviceIndex.upload(sc["hi"], gpu, seed_table=1, lc_long=14,
+                                            seed_table_share=2 if "share2" in long_table else None,
+                                            seed_table_bits=(14 if "share2" in long_table else 16) if "crowded" in long_table else None,
+                                            seed_table_count_bits=2 if "counts" in long_table else None)
+        t = di.tables()
+        if s_len_of(sc) == 20:
+            assert t["seed_table_len"] == 20 and t["seed_table_share"] == (2 if "share2" in long_table else 4), t
+            assert t["seed_table_slot_bytes"] == (6 if "share2" in long_table else 8), t
+            if "crowded" in long_table:
+                assert t["seed_table_side_entries"] > 1000, t
+    elif long_table != "auto":
+        own = di = index.DeviceIndex.upload(sc["hi"], gpu, seed_table=0, lc_long=int(long_table.split("-")[0]),
                                             lc_pair=0 if long_table.endswith("-plain") else None,
                                             lc_core=1 if long_table.endswith("-core") else 0,         # four positions per line
                                             lc_entry_bytes=5 if "5byte" in long_table else None,      # 40 bytes per (k-1)-mer
@@ -177,9 +195,15 @@ def test_seed_batch_vs_oracle(dev_indexes, gpu, name):
     for f in ("key", "val", "bucket"):
         assert np.array_equal(got[f], want[f]), (name, f, np.nonzero(got[f] != want[f])[0][:10])
     # the same through the long seed table (what large texts use automatically)
-    for tag, opts in (("long table", dict(lc_long=14)), ("pair-line 16-mers without the core table", dict(lc_long=16, lc_core=0)),
-                      ("5-byte long table", dict(lc_long=15, lc_entry_bytes=5)),
-                      ("5-byte long table, side hash table", dict(lc_long=14, lc_entry_bytes=5, lc_count_bits=2))):
+    for tag, opts in (("long table", dict(lc_long=14, seed_table=0)),
+                      ("pair-line 16-mers without the core table", dict(lc_long=16, lc_core=0, seed_table=0)),
+                      ("5-byte long table", dict(lc_long=15, lc_entry_bytes=5, seed_table=0)),
+                      ("5-byte long table, side hash table", dict(lc_long=14, lc_entry_bytes=5, lc_count_bits=2, seed_table=0)),
+                      ("lchash alone", dict(lc_long=0, seed_table=0)),
+                      ("seed table, two positions per line", dict(seed_table=1, seed_table_share=2, lc_long=13)),
+                      ("seed table, crowded lines", dict(seed_table=1, seed_table_bits=16, lc_long=13)),
+                      ("seed table, two positions per line, crowded, 2 count bits",
+                       dict(seed_table=1, seed_table_share=2, seed_table_bits=14, seed_table_count_bits=2, lc_long=13))):
         d2 = index.DeviceIndex.upload(sc["hi"], gpu, **opts)
         got = mapper.seed_batch(d2, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
         d2.close()
