@@ -136,19 +136,24 @@ __device__ __forceinline__ void lc_lookup(const LrmIndexView &ix, uint64_t code,
 //   << (48 - tagbits), the last four bytes of the line count its entries (> 10: overflowed).
 //   Entries that found no room, and counts of all ones, are in a side hash table keyed by the S-mer.
 // ----------------------------------------------------------------------------------------
-#define LRM_SD_MULT 0x9E3779B97F4A7C15ull
 struct SdKey { uint64_t line; uint64_t tag; uint32_t tb; };
+// (The kernel that looks seeds up here is bound by its VECTOR INSTRUCTIONS once a seed costs a quarter of a line -- 3.95 G
+//  wave-instructions per Gbp in 8.0 ms with a 64-bit multiplicative hash, 64-bit tag compares and a division per seed --
+//  so the hash is ONE 32-bit multiply: the low 32 bits of the core times an odd constant (a bijection of those bits whose
+//  TOP bits depend on all of them: they index the line), the bits of the core above 32 xor-ed with low bits of the product.)
 __device__ __forceinline__ SdKey sd_key_of(const LrmIndexView &ix, uint64_t code, uint32_t r) {
     const uint32_t lf = ix.sd_f == 4 ? 2u : 1u, F = 1u << lf, lo_n = F - 1u - r;
-    const uint32_t CL2 = 2u * ((uint32_t) ix.sd_len - F + 1u);
+    const uint32_t CL2 = 2u * ((uint32_t) ix.sd_len - F + 1u), wlo = CL2 < 32u ? CL2 : 32u;
     const uint64_t core = (code >> (2u * lo_n)) & ((1ull << CL2) - 1ull);
-    const uint64_t extra = (code & ((1ull << (2u * lo_n)) - 1ull)) | ((code >> (2u * lo_n + CL2)) << (2u * lo_n));
-    const uint64_t h = (core * LRM_SD_MULT) & ((1ull << CL2) - 1ull);            // odd multiplier: a bijection of the core
-    const uint32_t rb = CL2 - (uint32_t) ix.sd_bits;
+    const uint32_t extra = (uint32_t) (code & ((1ull << (2u * lo_n)) - 1ull)) | ((uint32_t) (code >> (2u * lo_n + CL2)) << (2u * lo_n));
+    uint32_t m = (uint32_t) core * 0x9E3779B1u;
+    if (wlo < 32u) m &= (1u << wlo) - 1u;
+    const uint32_t chi = ((uint32_t) (core >> 32) ^ m) & ((1u << (CL2 - wlo)) - 1u);          // (0 when the core has <= 32 bits)
+    const uint32_t rb = CL2 - (uint32_t) ix.sd_bits;                                          // < 32: sd_plan keeps sd_bits > CL2 - 32
     SdKey key;
-    key.line = h >> rb;
+    key.line = ((uint64_t) chi << (wlo - rb)) | (uint64_t) (m >> rb);
     key.tb = lf + 2u * (F - 1u) + rb;
-    key.tag = (uint64_t) r | (extra << lf) | ((h & ((1ull << rb) - 1ull)) << (lf + 2u * (F - 1u)));
+    key.tag = (uint64_t) (r | (extra << lf)) | ((uint64_t) (m & ((1u << rb) - 1u)) << (lf + 2u * (F - 1u)));
     return key;
 }
 // side table: true + entry (k | count << 40) when the S-mer is there
@@ -161,36 +166,61 @@ __device__ __forceinline__ bool sd_side_lookup(const LrmIndexView &ix, uint64_t 
         slot = (slot + 1) & ix.sdx_mask;
     }
 }
-// 0: absent (rr = 0); 1: k, c set; 2: take the other tables (a count beyond 24 bits)
-__device__ __forceinline__ int sd_lookup(const LrmIndexView &ix, uint64_t win, uint32_t jpar, uint64_t &k, uint64_t &c, uint32_t *cnt) {
-    const uint64_t code = win & ((1ull << (2 * ix.sd_len)) - 1ull);
-    const SdKey key = sd_key_of(ix, code, jpar & (uint32_t) (ix.sd_f - 1));
-    const uint64_t *line = ix.sd + key.line * 8;
-    // the whole line in ONE round trip (four independent 16-byte requests), searched in registers
-    const ulonglong2 x0 = *reinterpret_cast<const ulonglong2 *>(line), x1 = *reinterpret_cast<const ulonglong2 *>(line + 2);
-    const ulonglong2 x2 = *reinterpret_cast<const ulonglong2 *>(line + 4), x3 = *reinterpret_cast<const ulonglong2 *>(line + 6);
-    if (cnt) cnt[0] += 1;
-    const uint64_t W[8] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y, x3.x, x3.y};
+// search of a fetched line.  0: absent (rr = 0); 1: k, c set; 2: take the other tables (a count beyond 24 bits)
+// Slots fill from the front and an empty slot is all zeros, so the search runs from the LAST slot to the first with
+// `e = match ? slot : e`: an empty slot can only "match" a tag of zero, a real entry before it overrides it, and e == 0 in
+// the end means "not there".  The tag sits in the top bits of a slot: 32-bit compares on the high dword (8-byte slots, tags
+// of <= 32 bits) or on the third halfword (6-byte slots, tags of <= 16 bits: the 2^31-line table of a GRCh38-sized text).
+__device__ __forceinline__ int sd_search(const LrmIndexView &ix, const SdKey &key, uint64_t code, const uint64_t (&W)[8],
+                                         uint64_t &k, uint64_t &c, uint32_t *cnt) {
     uint64_t e = 0;
     bool ovf;
-    uint32_t sbits;
     if (ix.sd_slot == 8) {
-        sbits = 64;
+        if (key.tb <= 32u) {
+            const uint32_t sh = 32u - key.tb, t32 = (uint32_t) key.tag;
+            uint32_t elo = 0, ehi = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (W[i] != 0 && (W[i] >> (64u - key.tb)) == key.tag) e = W[i];
+            for (int i = 7; i >= 0; --i) {
+                const uint32_t hi = (uint32_t) (W[i] >> 32);
+                const bool m = (hi >> sh) == t32;
+                elo = m ? (uint32_t) W[i] : elo;
+                ehi = m ? hi : ehi;
+            }
+            e = (uint64_t) elo | ((uint64_t) ehi << 32);
+        } else {
+#pragma unroll
+            for (int i = 7; i >= 0; --i)
+                if ((W[i] >> (64u - key.tb)) == key.tag) e = W[i];
+        }
         ovf = (W[0] >> (63u - key.tb)) & 1ull;
     } else {
-        sbits = 48;
+        uint32_t D[16];
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            const int w = (48 * i) >> 6, off = (48 * i) & 63;
-            uint64_t v = W[w] >> off;
-            if (off > 16) v |= W[w + 1] << (64 - off);
-            v &= (1ull << 48) - 1ull;
-            if (v != 0 && (v >> (48u - key.tb)) == key.tag) e = v;
+        for (int i = 0; i < 8; ++i) { D[2 * i] = (uint32_t) W[i]; D[2 * i + 1] = (uint32_t) (W[i] >> 32); }
+        if (key.tb <= 16u) {
+            const uint32_t sh = 16u - key.tb, t32 = (uint32_t) key.tag;
+            uint32_t elo = 0, ehi = 0;
+#pragma unroll
+            for (int i = 9; i >= 0; --i) {
+                const int h2 = 3 * i + 2;                                              // the slot's third halfword: tag on top
+                const uint32_t hw = (h2 & 1) ? D[h2 >> 1] >> 16 : D[h2 >> 1] & 0xFFFFu;
+                const uint32_t lo = (i & 1) ? __builtin_amdgcn_alignbit(D[(3 * i + 1) >> 1], D[(3 * i) >> 1], 16) : D[(3 * i) >> 1];
+                const bool m = (hw >> sh) == t32;
+                elo = m ? lo : elo;
+                ehi = m ? hw : ehi;
+            }
+            e = (uint64_t) elo | ((uint64_t) ehi << 32);
+        } else {
+#pragma unroll
+            for (int i = 9; i >= 0; --i) {
+                const int w = (48 * i) >> 6, off = (48 * i) & 63;
+                uint64_t v = W[w] >> off;
+                if (off > 16) v |= W[w + 1] << (64 - off);
+                v &= (1ull << 48) - 1ull;
+                if ((v >> (48u - key.tb)) == key.tag) e = v;
+            }
         }
-        ovf = (uint32_t) (W[7] >> 32) > 10u;
+        ovf = D[15] > 10u;
     }
     const uint64_t cmax = (1ull << ix.sd_cbits) - 1ull;
     if (e != 0) {
@@ -200,7 +230,6 @@ __device__ __forceinline__ int sd_lookup(const LrmIndexView &ix, uint64_t win, u
     } else if (!ovf) {
         return 0;
     }
-    (void) sbits;
     uint64_t se;
     if (cnt) cnt[0] += 2;
     if (!sd_side_lookup(ix, code, se)) return e != 0 ? 2 : 0;           // (a saturated count without a side entry: never)
@@ -208,6 +237,62 @@ __device__ __forceinline__ int sd_lookup(const LrmIndexView &ix, uint64_t win, u
     k = se & ((1ull << 40) - 1ull);
     c = se >> 40;
     return 1;
+}
+// a lane on its own: the whole line in ONE round trip (four independent 16-byte requests), searched in registers
+__device__ __forceinline__ int sd_lookup(const LrmIndexView &ix, uint64_t win, uint32_t jpar, uint64_t &k, uint64_t &c, uint32_t *cnt) {
+    const uint64_t code = win & ((1ull << (2 * ix.sd_len)) - 1ull);
+    const SdKey key = sd_key_of(ix, code, jpar & (uint32_t) (ix.sd_f - 1));
+    const uint64_t *line = ix.sd + key.line * 8;
+    const ulonglong2 x0 = *reinterpret_cast<const ulonglong2 *>(line), x1 = *reinterpret_cast<const ulonglong2 *>(line + 2);
+    const ulonglong2 x2 = *reinterpret_cast<const ulonglong2 *>(line + 4), x3 = *reinterpret_cast<const ulonglong2 *>(line + 6);
+    if (cnt) cnt[0] += 1;
+    const uint64_t W[8] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y, x3.x, x3.y};
+    return sd_search(ix, key, code, W, k, c, cnt);
+}
+template <int CTRL>
+__device__ __forceinline__ uint64_t quad_perm64(uint64_t v) {
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) (uint32_t) v, CTRL, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) (uint32_t) (v >> 32), CTRL, 0xf, 0xf, true);
+    return (uint64_t) lo | ((uint64_t) hi << 32);
+}
+// The lanes of a wavefront hold CONSECUTIVE read positions (lane id == position, mod sd_f): the sd_f lanes that share a line
+// fetch it TOGETHER -- every lane one quarter (half) of the line of the group's first lane, a contiguous 64-byte request per
+// group instead of four 16-byte requests per lane -- and pass the pieces around inside the quad (DPP quad_perm: no LDS).
+// Every lane of the wavefront must be here (lanes without a seed come with win = 0 and ignore the answer); a lane whose
+// group's first lane has no seed has none either (positions grow with the lane id).
+// sd_issue_shared starts the fetch (the lane's piece: a, and b with two positions per line), sd_finish_shared gathers the
+// line and searches it.  (Keeping the fetches of 2 / 4 / 8 of a lane's seeds in flight between the two: 7.85 / 8.56 / 10.3 ms
+// per Gbp on the bench workload against 7.63 for one -- the kernel is not short of requests in flight.)
+__device__ __forceinline__ void sd_issue_shared(const LrmIndexView &ix, const SdKey &key, ulonglong2 &a, ulonglong2 &b) {
+    const uint32_t lane = __lane_id();
+    if (ix.sd_f == 4) {
+        const uint64_t line = quad_perm64<0x00>(key.line);                                    // quad_perm [0,0,0,0]
+        a = *reinterpret_cast<const ulonglong2 *>(ix.sd + line * 8 + (lane & 3u) * 2);
+        b = a;
+    } else {
+        const uint64_t line = quad_perm64<0xA0>(key.line);                                    // [0,0,2,2]
+        const uint64_t *src = ix.sd + line * 8 + (lane & 1u) * 4;
+        a = *reinterpret_cast<const ulonglong2 *>(src);
+        b = *reinterpret_cast<const ulonglong2 *>(src + 2);
+    }
+}
+__device__ __forceinline__ int sd_finish_shared(const LrmIndexView &ix, const SdKey &key, uint64_t code, const ulonglong2 &a, const ulonglong2 &b,
+                                                uint64_t &k, uint64_t &c, uint32_t *cnt) {
+    uint64_t W[8];
+    if (ix.sd_f == 4) {
+        W[0] = quad_perm64<0x00>(a.x); W[1] = quad_perm64<0x00>(a.y);
+        W[2] = quad_perm64<0x55>(a.x); W[3] = quad_perm64<0x55>(a.y);                         // [1,1,1,1]
+        W[4] = quad_perm64<0xAA>(a.x); W[5] = quad_perm64<0xAA>(a.y);                         // [2,2,2,2]
+        W[6] = quad_perm64<0xFF>(a.x); W[7] = quad_perm64<0xFF>(a.y);                         // [3,3,3,3]
+    } else {
+        const uint64_t pa = quad_perm64<0xB1>(a.x), pb = quad_perm64<0xB1>(a.y);              // [1,0,3,2]: the partner's half
+        const uint64_t pc = quad_perm64<0xB1>(b.x), pd = quad_perm64<0xB1>(b.y);
+        const bool odd = __lane_id() & 1u;
+        W[0] = odd ? pa : a.x; W[1] = odd ? pb : a.y; W[2] = odd ? pc : b.x; W[3] = odd ? pd : b.y;
+        W[4] = odd ? a.x : pa; W[5] = odd ? a.y : pb; W[6] = odd ? b.x : pc; W[7] = odd ? b.y : pd;
+    }
+    if (cnt) cnt[0] += 1;
+    return sd_search(ix, key, code, W, k, c, cnt);
 }
 
 // lc_aln (lchash.c:89-104) + fmi_aln (fmidx.c:295-313) on the packed read.
@@ -509,6 +594,7 @@ static bool sd_plan(const lrm_index *idx, uint64_t free_b, SdPlan *pl) {
         if (tu.sd_bits) bits = tu.sd_bits;
         const int CL2 = 2 * (S - f + 1);
         if (bits > CL2) bits = CL2;
+        if (bits < 11) bits = 11;                                                // (sd_key_of: fewer than 32 residue bits)
         const int tb = lf + 2 * (f - 1) + (CL2 - bits);
         int cbits = (slot == 8 ? 63 : 48) - tb - kbits;
         if (cbits < (tu.sd_bits ? 2 : 4) || tb > 40) continue;                  // (tests force few lines: long tags)
@@ -763,10 +849,55 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
     // SCALAR loads (one request per wavefront through the scalar cache instead of 64 lane requests through the
     // texture path) and every lane cuts its window out with selects and a funnel shift.
     const bool dense_lanes = (uint32_t) P - np <= 1u;
+    const bool shared_lines = ix.sd && seed_len == ix.sd_len && np == (uint32_t) P && phase_lo == 0;
+    LrmIndexView ix_nosd = ix;
+    ix_nosd.sd = nullptr;
+    if (shared_lines) {
+        // All phases in this launch: a lane's item IS its read position j, lane id == j mod sd_f, and the lanes that share a
+        // line of the seed table fetch it together (sd_issue_shared): every lane of the wavefront stays in until the line is
+        // in registers.
+        const uint32_t lim = jl < cap_q * np ? jl : cap_q * np;                                     // positions with a seed
+        const uint32_t np_inv = 0xFFFFFFFFu / np;
+        const uint64_t smask = (1ull << (2 * seed_len)) - 1ull;
+#pragma unroll 1
+        for (uint32_t it = 0; it < SS_ITEMS / 256; ++it) {
+            const uint32_t j = chunk * SS_ITEMS + it * 256 + tid;
+            const bool have = j < lim;
+            const uint32_t j0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) (j & ~63u));        // lane 0's position: a multiple of 64
+            if (j0 >= lim) break;                                                                  // (positions only grow)
+            const uint64_t *wp = words + (j0 >> 5);                                                // wave-uniform address: scalar loads
+            const uint64_t W0 = wp[0], W1 = wp[1], W2 = wp[2];
+            const uint32_t rel = j - j0, sh = (rel & 31u) * 2u;
+            const uint64_t lo = rel < 32u ? W0 : W1, hi = rel < 32u ? W1 : W2;
+            const uint64_t code = have ? ((lo >> sh) | ((hi << 1) << (63 - sh))) & smask : 0ull;
+            const SdKey key = sd_key_of(ix, code, j & (uint32_t) (ix.sd_f - 1));
+            ulonglong2 xa, xb;
+            sd_issue_shared(ix, key, xa, xb);
+            uint64_t k = 0, l = 0, c = 0, rr;
+            const int st = sd_finish_shared(ix, key, code, xa, xb, k, c, COUNT ? my_cnt : nullptr);
+            if (!have) continue;
+            if (st == 1) rr = c;
+            else if (st == 0) rr = 0;
+            else rr = seed_one(ix_nosd, code, seed_len, j, k, l, COUNT ? my_cnt : nullptr);           // (a count beyond 24 bits)
+            if (COUNT) my_seeds++;
+            if (rr > 0 && rr < (uint64_t) thres) {
+                uint32_t q = __umulhi(j, np_inv), ph = j - q * np;                                  // j / np, j % np without a division
+                if (ph >= np) { ++q; ph -= np; }
+                if (ph >= np) { ++q; ph -= np; }
+                const uint32_t slot = atomicAdd(&s_cnt[ph], 1u);
+                atomicAdd(&s_hits[ph], (uint32_t) rr);
+                s_rec[ph * cap_pp + slot] = k | (rr << 40);
+                s_q[ph * cap_pp + slot] = q;
+            }
+        }
+    } else {
+    const uint32_t np_inv_g = 0xFFFFFFFFu / np;
 #pragma unroll 1
     for (uint32_t it = 0; it < SS_ITEMS / 256; ++it) {
         const uint32_t item = chunk * SS_ITEMS + it * 256 + tid;
-        const uint32_t q = item / np, ph = item % np;
+        uint32_t q = __umulhi(item, np_inv_g), ph = item - q * np;             // item / np, item % np without a division
+        if (ph >= np) { ++q; ph -= np; }
+        if (ph >= np) { ++q; ph -= np; }
         uint64_t W[6] = {0, 0, 0, 0, 0, 0};
         uint32_t jw = 0;                                                       // first base of W[0]
         if (dense_lanes) {
@@ -783,7 +914,7 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
         if (q >= cap_q) break;
         const uint32_t j = (uint32_t) phase_lo + ph + q * (uint32_t) P;        // < 2^32: cap_q * P <= max_len + P
         if (j >= jl) continue;
-        uint64_t win;
+        uint64_t win, k, l;
         if (dense_lanes) {
             const uint32_t rel = j - jw, wi = rel >> 5, sh = (rel & 31u) * 2u;  // rel <= 31 + 63 + 4: wi in 0..3
             const uint64_t lo = wi == 0 ? W[0] : wi == 1 ? W[1] : wi == 2 ? W[2] : wi == 3 ? W[3] : W[4];
@@ -792,7 +923,6 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
         } else {
             win = read_window(words, j);
         }
-        uint64_t k, l;
         const uint64_t rr = seed_one(ix, win, seed_len, j, k, l, COUNT ? my_cnt : nullptr);
         if (COUNT) my_seeds++;
         if (rr > 0 && rr < (uint64_t) thres) {
@@ -801,6 +931,7 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
             s_rec[ph * cap_pp + slot] = k | (rr << 40);
             s_q[ph * cap_pp + slot] = q;
         }
+    }
     }
     if (COUNT) { atomicAdd(&s_traffic[0], my_seeds); atomicAdd(&s_traffic[1], my_cnt[0]); atomicAdd(&s_traffic[2], my_cnt[1]); }
     __syncthreads();
@@ -814,8 +945,10 @@ __global__ __launch_bounds__(256) void seed_search_kernel(LrmIndexView ix, const
         }
     }
     __syncthreads();
+    const uint32_t cpp_inv = 0xFFFFFFFFu / cap_pp;                         // e / cap_pp without a division (e < 2^16: exact after one fix-up)
     for (uint32_t e = tid; e < np * cap_pp; e += 256) {
-        const uint32_t ph = e / cap_pp, sl = e - ph * cap_pp;
+        uint32_t ph = __umulhi(e, cpp_inv), sl = e - ph * cap_pp;
+        if (sl >= cap_pp) { ++ph; sl -= cap_pp; }
         if (sl < s_cnt[ph]) {
             const uint64_t o = (read * (uint64_t) P + (uint64_t) (phase_lo + (int) ph)) * cap_q + s_base[ph] + sl;
             rec[o] = s_rec[e];
