@@ -551,6 +551,15 @@ def main():
             rr["note"] = ("integer DP (gact): bound by VALU issue, not by HBM or MFMA -- its HBM fraction is small by "
                           "construction (%.1f B/base, %.0f cells/base); see valu_issue_frac / gcups"
                           % (per_base["gact"], per_base["cells"]))
+            if "valu_issue_frac" in rr:
+                # The roofline this kernel really has: integer vector-instruction issue (no matrix work, 3 bytes per base of HBM
+                # traffic).  `bound` steps outside the contract's hbm|mfma on purpose -- neither is what limits a bit-sliced
+                # integer DP -- and the HBM figures stay next to it under hbm_*.
+                rr.update(hbm_achieved=rr["achieved"], hbm_peak=rr["peak"], hbm_frac=rr["frac"], hbm_unit=rr["unit"],
+                          bound="valu", achieved=k["valu_wave_insts_per_launch"] / sec / 1e9, peak=1024 * 2.4 / 4,
+                          unit="G wave64 instructions/s", frac=rr["valu_issue_frac"],
+                          achieved_definition="vector wave-instructions per launch (committed rocprofv3 --pmc pass, SQ_INSTS_VALU) / average "
+                                              "launch time of the serialized replay; peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction")
         return rr
 
     kernels, dominant = kernel_table(ktimes)

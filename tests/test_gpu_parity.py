@@ -215,6 +215,19 @@ def test_seed_batch_vs_oracle(dev_indexes, gpu, name):
             for f in ("key", "val", "bucket"):
                 assert np.array_equal(got[f], want[f]), (name, f, tag, "one round")
         d2.close()
+    if name == "seed16":
+        # a seed table built for THIS seed length: four positions per line (26-bit cores: the hash keeps fewer than 32 bits)
+        # and two (6-byte slots whose 15-bit tags are compared as halfwords -- the form a GRCh38-sized text takes)
+        for share in (4, 2):
+            d2 = index.DeviceIndex.upload(sc["hi"], gpu, seed_table=1, seed_table_len=16, seed_table_share=share, lc_long=13)
+            t = d2.tables()
+            assert t["seed_table_len"] == 16 and t["seed_table_share"] == share and t["seed_table_slot_bytes"] == (8 if share == 4 else 6), t
+            for rounds in (0, 1):
+                d2.set_map_options(seed_rounds=rounds)
+                got = mapper.seed_batch(d2, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])
+                for f in ("key", "val", "bucket"):
+                    assert np.array_equal(got[f], want[f]), (name, f, share, rounds)
+            d2.close()
     if name == "clean-1k":
         assert (phases == 1).mean() > 0.7          # exercised the phase-0 early decision
     if name == "ont-2k":

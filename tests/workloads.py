@@ -63,6 +63,10 @@ def scenario(name):
         seqs = [synth.reference(100_000, seed=8)]
         r = synth.reads(seqs, 32, 900, synth.ONT, seed=31)
         sc = dict(seqs=seqs, seed_len=12, thres=300, hlen=12)
+    elif name == "seed16":            # shortest seed the seed table takes: cores of 26 / 30 bits, 6-byte slots with halfword tags
+        seqs = [synth.reference(180_000, seed=14), synth.reference(30_000, seed=15)]
+        r = synth.reads(seqs, 48, 1500, synth.ONT, seed=33)
+        sc = dict(seqs=seqs, seed_len=16, thres=300, hlen=8)
     elif name == "seed32":            # longest supported seed
         seqs = [synth.reference(100_000, seed=9)]
         r = synth.reads(seqs, 32, 1500, dict(p_sub=0.01, p_ins=0.01, p_del=0.01), seed=37)
@@ -84,4 +88,4 @@ def scenario(name):
 
 
 SEED_SCENARIOS = ["clean-1k", "ont-2k", "pacbio-3k-h12", "ragged", "repeats-ties", "repeats-overflow", "seed12",
-                  "seed32", "seed-below-hlen", "last-phase-break"]
+                  "seed16", "seed32", "seed-below-hlen", "last-phase-break"]
