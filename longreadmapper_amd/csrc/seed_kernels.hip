@@ -156,6 +156,7 @@ __device__ __forceinline__ SdKey sd_key_of(const LrmIndexView &ix, uint64_t code
     key.tag = (uint64_t) (r | (extra << lf)) | ((uint64_t) (m & ((1u << rb) - 1u)) << (lf + 2u * (F - 1u)));
     return key;
 }
+__device__ __forceinline__ uint32_t sd_filter_bit(uint32_t tag) { return (((tag * 0x9E3779B1u) >> 27) * 24u) >> 5; }   // 0 .. 23
 // side table: true + entry (k | count << 40) when the S-mer is there
 __device__ __forceinline__ bool sd_side_lookup(const LrmIndexView &ix, uint64_t code, uint64_t &e) {
     uint64_t slot = (code * 0x9E3779B97F4A7C15ull) >> 20 & ix.sdx_mask;
@@ -220,7 +221,9 @@ __device__ __forceinline__ int sd_search(const LrmIndexView &ix, const SdKey &ke
                 if ((v >> (48u - key.tb)) == key.tag) e = v;
             }
         }
-        ovf = D[15] > 10u;
+        // the line's last word: entry count in the low byte; above it a 24-bit filter of the tags that found no room -- a seed
+        // the text does not hold (most seeds of a noisy read) goes on to the side table only when its filter bit is set
+        ovf = (D[15] & 0xFFu) > 10u && ((D[15] >> (8u + sd_filter_bit((uint32_t) key.tag))) & 1u);
     }
     const uint64_t cmax = (1ull << ix.sd_cbits) - 1ull;
     if (e != 0) {
@@ -554,7 +557,9 @@ __global__ __launch_bounds__(256) void sd_build_kernel(LrmIndexView ix, LrmIndex
             if (!placed) atomicOr((unsigned long long *) &line[0], 1ull << (63u - key.tb));
         } else {
             const uint64_t v = k | (c << sdv.sd_kbits) | (key.tag << (48u - key.tb));
-            const uint32_t at = atomicAdd(reinterpret_cast<uint32_t *>(line) + 15, 1u);
+            const uint32_t at = atomicAdd(reinterpret_cast<uint32_t *>(line) + 15, 1u) & 0xFFu;
+            if (at >= 250u) atomicAdd(n_ovf, 1ull << 40);                                     // (the count byte would run into the filter: give the table up)
+            if (at >= 10u) atomicOr(reinterpret_cast<uint32_t *>(line) + 15, 1u << (8u + sd_filter_bit((uint32_t) key.tag)));
             if (at < 10u) {
                 uint16_t *h = reinterpret_cast<uint16_t *>(line) + 3 * at;                   // three 2-byte stores: slots are 6 bytes apart
                 h[0] = (uint16_t) v; h[1] = (uint16_t) (v >> 16); h[2] = (uint16_t) (v >> 32);
