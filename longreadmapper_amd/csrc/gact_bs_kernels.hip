@@ -34,7 +34,9 @@
 #include <cstdlib>
 #include "lrm_internal.h"
 
+#ifndef BS_K
 #define BS_K 32                 // anti-diagonals per traceback block (even, <= 32)
+#endif
 #define BS_H (BS_K / 2)
 #define LRM_BS_MAX_WAVES 2048ull  // 2 per SIMD on 256 CUs
 #define BS_PADW LRM_BS_PADW
