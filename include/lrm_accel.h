@@ -156,7 +156,13 @@ typedef struct lrm_map_options {
     uint32_t copy_threads;     /* memcpy team of the PAGEABLE paths (upload staging, result placement): 0 automatic (the host's CPU
                                   share / replicas, at most 8 -- what 24 Gbp/s through pageable buffers needs), else 1..16; a caller
                                   whose own threads need the cores (lrm_accaln's parser and formatter) says 1 or 2 */
-    uint32_t reserved[8];
+    uint32_t keep_reads;       /* 1: reads_buf is left exactly as the caller gave it -- the reverse-complemented copies of the
+                                  reverse-strand reads (alnmain.c:437 does that in place, before the extension) stay on the device,
+                                  0.5 bytes per read base less cross the link and nothing is placed on the host.  A caller that
+                                  prints such a read (SAM SEQ) applies meta_out[i].strand itself: the read was reverse-complemented
+                                  iff meta_r[i] != 0 && meta_out[i].strand == 1 (lrm_accaln's formatter does).  Host-buffer
+                                  batch calls only. */
+    uint32_t reserved[7];
 } lrm_map_options;
 void lrm_map_options_init(lrm_map_options *o);
 

@@ -77,7 +77,7 @@ class MapOptions(C.Structure):         # lrm_map_options
     _fields_ = [("struct_size", C.c_uint32), ("dense_results", C.c_int32), ("gact_impl", C.c_int32),
                 ("seed_rounds", C.c_int32), ("vote_exact_only", C.c_int32), ("slice_reads", C.c_uint32),
                 ("sub_batches", C.c_uint32), ("group_subs", C.c_uint32), ("bs_waves", C.c_uint32),
-                ("cigar_text", C.c_uint32), ("copy_threads", C.c_uint32), ("reserved", C.c_uint32 * 8)]
+                ("cigar_text", C.c_uint32), ("copy_threads", C.c_uint32), ("keep_reads", C.c_uint32), ("reserved", C.c_uint32 * 7)]
 
 
 class Stats(C.Structure):

@@ -534,12 +534,15 @@ extern "C" char *lrm_sam_header(const lrm_mta_entry *mta, int mta_len, long rg_i
     return dup_out(s, len_out);
 }
 
+// _rev_comp_in_place's base map (alnmain.c:29-52): ACGT of either case -> upper-case complement, anything else -> 'N'
+static const struct CompTable { char t[256]; CompTable() { for (int c = 0; c < 256; ++c) t[c] = 'N'; t['A'] = t['a'] = 'T'; t['C'] = t['c'] = 'G'; t['G'] = t['g'] = 'C'; t['T'] = t['t'] = 'A'; } } k_comp;
+
 // SAM lines of reads [lo, hi) appended to s (alnmain.c:500-525 field for field).  No snprintf on the hot path: a 10 kbp
 // ONT read has ~2000 CIGAR runs.
 // cigar_is_text: cig[i].cigar is the NUL-terminated run-length text already (lrm_map_options.cigar_text), not op bytes.
 static void sam_format_range(const lrm_read_batch *reads, const lrm_mta_entry *mta, int mta_len, const lrm_cigar *cig,
                              const int *score, const lrm_seq_meta *meta, const int *meta_r, uint64_t lo, uint64_t hi,
-                             std::string &s, bool cigar_is_text) {
+                             std::string &s, bool cigar_is_text, bool revcomp_here) {
     uint64_t est = 0;
     for (uint64_t i = lo; i < hi; ++i) est += 2ull * reads->lens[i] + 2ull * (cig[i].n_cigar_op > 0 ? (uint64_t) cig[i].n_cigar_op : 0) + 160;
     s.clear();
@@ -573,7 +576,16 @@ static void sam_format_range(const lrm_read_batch *reads, const lrm_mta_entry *m
             s += '*';
         }
         s += "\t*\t0\t0\t";                                            // r_name "*", 0L, 0
-        s.append(reads->seqs + i * reads->stride, len);               // the (possibly rev-comped) read
+        if (revcomp_here && meta_r[i] != 0 && meta[i].strand == 1) {
+            // lrm_map_options.keep_reads: the batch came back as it went -- _rev_comp_in_place (alnmain.c:27-60) while copying
+            const size_t at = s.size();
+            s.resize(at + len);
+            const char *src = reads->seqs + i * reads->stride;
+            char *dst = &s[at];
+            for (uint32_t x = 0; x < len; ++x) dst[x] = k_comp.t[(uint8_t) src[len - 1 - x]];
+        } else {
+            s.append(reads->seqs + i * reads->stride, len);           // the (possibly rev-comped) read
+        }
         s += '\t';
         if (reads->quals[i]) s.append(reads->quals[i], len); else s += '*';
         s += "\tED:I:";
@@ -586,14 +598,14 @@ static void sam_format_range(const lrm_read_batch *reads, const lrm_mta_entry *m
 // Every thread formats a contiguous range of reads into its own buffer.
 static void sam_format_parts(const lrm_read_batch *reads, const lrm_mta_entry *mta, int mta_len, const lrm_cigar *cig,
                              const int *score, const lrm_seq_meta *meta, const int *meta_r, uint64_t n, int nt,
-                             std::vector<std::string> &parts, bool cigar_is_text = false) {
+                             std::vector<std::string> &parts, bool cigar_is_text = false, bool revcomp_here = false) {
     if (nt < 1) nt = 1;
     if ((uint64_t) nt > n) nt = n ? (int) n : 1;
     parts.resize((size_t) nt);
 #pragma omp parallel for schedule(static, 1) num_threads(nt)
     for (int t = 0; t < nt; ++t)
         sam_format_range(reads, mta, mta_len, cig, score, meta, meta_r, n * (uint64_t) t / (uint64_t) nt, n * (uint64_t) (t + 1) / (uint64_t) nt,
-                         parts[(size_t) t], cigar_is_text);
+                         parts[(size_t) t], cigar_is_text, revcomp_here);
 }
 
 extern "C" char *lrm_sam_format(const lrm_read_batch *reads, const lrm_mta_entry *mta, int mta_len,
@@ -727,6 +739,7 @@ extern "C" int lrm_accaln(const char *genome, const char *reads_path, const char
         lrm_map_options_init(&mopt);
         mopt.cigar_text = 1;                        // parse_cigar (alnmain.c:497-498) runs on the device: the SAM CIGAR text comes back
         mopt.copy_threads = 2;                      // the parser and the formatter need the cores
+        mopt.keep_reads = 1;                        // reverse-strand reads are reverse-complemented by the formatter as it copies them
         // Pinning the batch buffers (0.2 s per GB to pin and to release, and the device stalls while the runtime pins)
         // pays from a few tens of Gbp on: reads files below 16 GiB run through pageable buffers.
         bool want_pinned = false;
@@ -791,7 +804,7 @@ extern "C" int lrm_accaln(const char *genome, const char *reads_path, const char
                     const uint64_t n = s->b.n;
                     const double t0 = now();
                     sam_format_parts(&s->b, hi.mta, hi.mta_len, s->cig.data(), s->score.data(), s->meta.data(), s->meta_r.data(), n,
-                                     io_threads, tb->parts, /* cigar_is_text */ true);
+                                     io_threads, tb->parts, /* cigar_is_text */ true, /* revcomp_here */ true);
                     t_fmt += now() - t0;
                     if (verbose) fprintf(stderr, "[lrm accaln] %.3f formatted %llu reads in %.3f s\n", now() - t_upload, (unsigned long long) n, now() - t0);
                     total += n;

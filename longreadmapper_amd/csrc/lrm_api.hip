@@ -145,6 +145,7 @@ void lrm_resolve_map_tune(const lrm_map_options *opt, const LrmEnv &env, LrmMapT
     t->gact_impl = o.gact_impl; t->seed_rounds = o.seed_rounds;
     t->slice_reads = o.slice_reads; t->sub_batches = o.sub_batches; t->group_subs = o.group_subs; t->bs_waves = o.bs_waves;
     t->copy_threads = o.copy_threads <= 16 ? o.copy_threads : 16;
+    t->keep_reads = o.keep_reads != 0;
     // measured defaults of the kernel knobs (tools/seed_probe.py sweeps them through the environment)
     t->ss_items = 2048; t->vote_vg = 16; t->vote_t1 = LRM_VOTE_T1_LIMIT; t->vote_u = 2; t->vote_load = 50; t->vote_fast = o.vote_exact_only ? 0 : 1;
     t->ext_streams = 2; t->seed_streams = 2;

@@ -36,6 +36,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <functional>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -101,7 +103,7 @@ struct PinSlot {
 
 constexpr uint64_t STAGE_CHUNK = 32ull << 20;      // pinned chunks of the pageable upload staging
 constexpr uint64_t RING_CHUNK = 16ull << 20;       // ... and of the download ring
-constexpr int N_RING = 4;
+constexpr int N_RING = 16;          // 256 MiB of pinned chunks per replica: a unit's reverse-complemented reads (0.25 GB) fit whole
 constexpr int N_SEED_STREAMS = 3;
 constexpr int N_EXT_STREAMS = 4;
 constexpr int N_SLOTS = 3;            // upper bound on the batches (slices) in flight per replica; n_slots of them are used
@@ -605,6 +607,11 @@ int plan_and_issue(LrmHostCtx &c, SliceJob &sj) {
         }
         if (sj.clk.on) fprintf(stderr, "[lrm host] issue   off=%llu m=%llu: %.1f -> %.1f ms\n", (unsigned long long) off, (unsigned long long) m, t_i0, sj.clk.ms());
     }
+    if (sj.clk.on) {
+        timespec ts;
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+        fprintf(stderr, "[lrm host] slice issued at %.1f ms (issuer thread CPU so far %.1f ms)\n", sj.clk.ms(), ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6);
+    }
     return 0;
 }
 
@@ -670,7 +677,7 @@ int collect(LrmHostCtx &c, SliceJob &sj, size_t g) {
     total = total_ops;
     uint64_t n_rev = 0;
     for (uint64_t i = 0; i < m; ++i) {
-        const bool rev = h_mr[i] != 0 && h_meta[i].strand == 1;
+        const bool rev = !sj.mt.keep_reads && h_mr[i] != 0 && h_meta[i].strand == 1;   // (keep_reads: the caller's buffer stays as it is)
         h_len[m + i] = rev ? j.lens[o + i] : 0u;
         h_off[m + i] = total;
         total += ((uint64_t) h_len[m + i] + 15) & ~15ull;
@@ -706,6 +713,12 @@ int collect(LrmHostCtx &c, SliceJob &sj, size_t g) {
             // this thread alone.  Then the op bytes: ONE DMA straight into the region of the caller's pinned store_mem
             // the unit's rows would occupy (sum of the 16-aligned lengths <= m * store_stride because
             // store_stride % 16 == 0) -- it flies while this thread goes on to the next unit.
+            // The ring is deep enough (N_RING chunks) for every piece of a unit's reads to be handed to the DMA engine before
+            // the first is drained, so the op bytes follow right behind them on the same stream and fly while this thread
+            // places the reads.  (With four chunks the op bytes waited until the collector had copied nearly all of
+            // the reads through them: 48 ms per batch on a box with a slow host memcpy against 32 with keep_reads, whose op
+            // bytes leave at once; the op bytes on a second stream next to the ring: 38-40 ms -- two blit copies at a time
+            // share the link badly; helper threads for the placement: no difference.)
             auto ops_dma = [&]() -> int {
                 if (total_ops && pin_store) HIPCHK(hipMemcpyAsync(h_store, dn, total_ops, hipMemcpyDeviceToHost, c.down));
                 return 0;
@@ -814,8 +827,12 @@ void collector_main(LrmHostCtx *cp) {
             (void) hipStreamSynchronize(c.down);
             (void) take_errors(S);                                        // reported now: do not fail the next batch
         }
-        if (sj.clk.on) fprintf(stderr, "[lrm host] slice of %llu reads, %zu seed sub-batches, %zu units: %.1f ms\n", (unsigned long long) sj.j.n,
-                               sj.subs.size(), sj.units.size(), sj.clk.ms());
+        if (sj.clk.on) {
+            timespec ts;
+            clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+            fprintf(stderr, "[lrm host] slice of %llu reads, %zu seed sub-batches, %zu units: %.1f ms (collector thread CPU so far %.1f ms)\n", (unsigned long long) sj.j.n,
+                    sj.subs.size(), sj.units.size(), sj.clk.ms(), ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6);
+        }
         lrm_ticket *t = sj.ticket;
         job.reset();
         {

@@ -112,7 +112,7 @@ struct LrmIndexTune {
     uint64_t lcx_threshold;
 };
 struct LrmMapTune {
-    int dense, gact_impl, seed_rounds, cigar_text;
+    int dense, gact_impl, seed_rounds, cigar_text, keep_reads;
     uint32_t slice_reads, sub_batches, group_subs, bs_waves, copy_threads;
     uint32_t ss_items, ss_lds_pad, vote_vg, vote_t1, vote_u, vote_load, vote_fast;      // kernel tuning (environment only; measured defaults)
     uint32_t t3_limit, t3_slots;                                 // lrm_debug_set_vote_limits (tests)

@@ -592,7 +592,7 @@ static bool sd_plan(const lrm_index *idx, uint64_t free_b, SdPlan *pl) {
     while ((1ull << kbits) < L) ++kbits;
     for (int f = 4; f >= 2; f -= 2) {
         if (tu.sd_f && tu.sd_f != f) continue;
-        const int slot = f == 4 ? 8 : 6, lf = f == 4 ? 2 : 1, per_line = f == 4 ? 8 : 10;
+        const int slot = f == 4 ? 8 : 6, lf = f == 4 ? 2 : 1;
         const double target = f == 4 ? 2.2 : 6.0;
         int bits = 10;
         while ((double) f * (double) L / (double) (1ull << bits) > target && bits < 34) ++bits;
@@ -606,7 +606,6 @@ static bool sd_plan(const lrm_index *idx, uint64_t free_b, SdPlan *pl) {
         if (cbits > 24) cbits = 24;
         if (tu.sd_cbits && tu.sd_cbits < cbits) cbits = tu.sd_cbits;
         const uint64_t bytes = 64ull << bits;
-        (void) per_line;
         // room: the table, its side table (<= 1/8 of it) and what the batch workspaces need afterwards
         const uint64_t spare = bytes >= (32ull << 30) ? (40ull << 30) : (8ull << 30);
         if (tu.sd < 0 && ((uint64_t) free_b < bytes + bytes / 8 + spare || (tu.lc_long_max >= 13 && bytes > (16ull << 30)))) continue;

@@ -46,7 +46,8 @@ def _dense_rows(got):
 
 
 @pytest.mark.parametrize("opts", [None, {}, {"sub_batches": 4}, {"slice_reads": 9, "sub_batches": 2},
-                                  {"dense_results": 1}, {"dense_results": 1, "slice_reads": 13, "sub_batches": 3, "group_subs": 1}])
+                                  {"dense_results": 1}, {"dense_results": 1, "slice_reads": 13, "sub_batches": 3, "group_subs": 1},
+                                  {"keep_reads": 1}, {"dense_results": 1, "keep_reads": 1, "sub_batches": 3}])
 def test_map_batch_equals_the_two_calls_and_the_oracle(ont, opts):
     """lrm_map_batch = lrm_seed_batch + lrm_extend_batch in one device pass (one upload of the reads), in every result
     mode of lrm_map_options: rows / dense, any slicing."""
@@ -60,7 +61,15 @@ def test_map_batch_equals_the_two_calls_and_the_oracle(ont, opts):
         got = _dense_rows(got)
     assert np.array_equal(got["best"], best)
     _assert_ext_equal(got, ext, len(best), str(opts))
-    assert np.array_equal(r, r_cpu)                      # reverse-strand reads rev-comped in the caller's buffer
+    if opts and opts.get("keep_reads"):
+        # the caller's buffer comes back as it went; strand and meta_r say which reads the reference would have
+        # reverse-complemented in place (alnmain.c:437) -- exactly the rows in which the oracle's buffer differs
+        assert np.array_equal(r, sc["reads"])
+        rev = (got["meta_r"] != 0) & (got["meta"]["strand"] == 1)
+        changed = (r_cpu != sc["reads"]).any(axis=1)
+        assert rev.any() and np.array_equal(changed, rev & (sc["lens"] > 0))
+    else:
+        assert np.array_equal(r, r_cpu)                  # reverse-strand reads rev-comped in the caller's buffer
 
 
 @pytest.mark.parametrize("opts", [{}, {"dense_results": 1}])
