@@ -599,7 +599,8 @@ static bool sd_plan(const lrm_index *idx, uint64_t free_b, SdPlan *pl) {
         if (tu.sd_bits) bits = tu.sd_bits;
         const int CL2 = 2 * (S - f + 1);
         if (bits > CL2) bits = CL2;
-        if (bits < 11) bits = 11;                                                // (sd_key_of: fewer than 32 residue bits)
+        if (bits < 11) bits = 11;
+        if (bits < CL2 - 31) bits = CL2 - 31;                                    // (sd_key_of: fewer than 32 residue bits)
         const int tb = lf + 2 * (f - 1) + (CL2 - bits);
         int cbits = (slot == 8 ? 63 : 48) - tb - kbits;
         if (cbits < (tu.sd_bits ? 2 : 4) || tb > 40) continue;                  // (tests force few lines: long tags)

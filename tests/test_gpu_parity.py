@@ -215,13 +215,16 @@ def test_seed_batch_vs_oracle(dev_indexes, gpu, name):
             for f in ("key", "val", "bucket"):
                 assert np.array_equal(got[f], want[f]), (name, f, tag, "one round")
         d2.close()
-    if name == "seed16":
-        # a seed table built for THIS seed length: four positions per line (26-bit cores: the hash keeps fewer than 32 bits)
-        # and two (6-byte slots whose 15-bit tags are compared as halfwords -- the form a GRCh38-sized text takes)
+    if name in ("seed16", "seed24"):
+        # a seed table built for THIS seed length.  16: four positions per line (26-bit cores: the hash keeps fewer than 32
+        # bits) and two (6-byte slots whose 15-bit tags are compared as halfwords -- the form a GRCh38-sized text takes);
+        # 24: cores of 42 / 46 bits, the bits above 32 folded into the line index
         for share in (4, 2):
-            d2 = index.DeviceIndex.upload(sc["hi"], gpu, seed_table=1, seed_table_len=16, seed_table_share=share, lc_long=13)
+            # (6-byte slots have room for the 46-bit core's tag only with many lines: a small text gets them by hand)
+            d2 = index.DeviceIndex.upload(sc["hi"], gpu, seed_table=1, seed_table_len=sc["seed_len"], seed_table_share=share, lc_long=13,
+                                          seed_table_bits=24 if (name == "seed24" and share == 2) else None)
             t = d2.tables()
-            assert t["seed_table_len"] == 16 and t["seed_table_share"] == share and t["seed_table_slot_bytes"] == (8 if share == 4 else 6), t
+            assert t["seed_table_len"] == sc["seed_len"] and t["seed_table_share"] == share and t["seed_table_slot_bytes"] == (8 if share == 4 else 6), t
             for rounds in (0, 1):
                 d2.set_map_options(seed_rounds=rounds)
                 got = mapper.seed_batch(d2, sc["reads"], sc["lens"], sc["seed_len"], sc["thres"])

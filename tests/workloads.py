@@ -67,6 +67,10 @@ def scenario(name):
         seqs = [synth.reference(180_000, seed=14), synth.reference(30_000, seed=15)]
         r = synth.reads(seqs, 48, 1500, synth.ONT, seed=33)
         sc = dict(seqs=seqs, seed_len=16, thres=300, hlen=8)
+    elif name == "seed24":            # longest seed the seed table takes: cores of 42 / 46 bits (the hash folds the bits above 32 in)
+        seqs = [synth.reference(120_000, seed=16)]
+        r = synth.reads(seqs, 40, 1200, dict(p_sub=0.02, p_ins=0.01, p_del=0.01), seed=35)
+        sc = dict(seqs=seqs, seed_len=24, thres=300, hlen=8)
     elif name == "seed32":            # longest supported seed
         seqs = [synth.reference(100_000, seed=9)]
         r = synth.reads(seqs, 32, 1500, dict(p_sub=0.01, p_ins=0.01, p_del=0.01), seed=37)
@@ -88,4 +92,4 @@ def scenario(name):
 
 
 SEED_SCENARIOS = ["clean-1k", "ont-2k", "pacbio-3k-h12", "ragged", "repeats-ties", "repeats-overflow", "seed12",
-                  "seed16", "seed32", "seed-below-hlen", "last-phase-break"]
+                  "seed16", "seed24", "seed32", "seed-below-hlen", "last-phase-break"]
