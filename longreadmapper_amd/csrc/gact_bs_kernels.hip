@@ -254,9 +254,10 @@ __device__ __forceinline__ void bs_half(uint32_t u1, uint32_t u0, uint32_t w1, u
     const uint32_t nd = BS_LOP3(m, u1, w1, ~TA & (TB | TC));               // a gap beats the mismatch diagonal
     const uint32_t d0 = u0 ^ w0;
     const uint32_t d1 = BS_LOP3(u1, w1, b0, TA ^ TB ^ TC);                 // (u - w) mod 4 = d1 d0
-    const uint32_t del = nd & lt;
-    const uint32_t a = BS_LOP3(del, d1, d0, TA & (TB ^ TC));               // high bit of w - u, deletions only
-    uint32_t v1 = BS_LOP3(a, m, u1, TA | (TB & ~TC));
+    // high bit of w - u for u < w: w - u >= 2 needs w >= 1 (code >= 2), i.e. w1 set, so the lattice point is a gap point
+    // (nd) unless the bases match -- `nd & lt` need not be formed: the match bit gates it in the next instruction
+    const uint32_t a = BS_LOP3(lt, d1, d0, TA & (TB ^ TC));
+    uint32_t v1 = BS_LOP3(a, m, u1, (TA & ~TB) | (TB & ~TC));               // match ? ~u1 : a
     const uint32_t hh = BS_LOP3(nd, lt, d1, TA & ~TB & TC);
     uint32_t h1 = BS_LOP3(hh, m, w1, TA | (TB & ~TC));
     const uint32_t x = BS_LOP3(nd, lt, d0, TA & TB & TC);
