@@ -106,6 +106,15 @@ __device__ __forceinline__ uint64_t sa_locate(const LrmIndexView &ix, uint64_t r
     return ix.sa[row >> ix.sa_shift] + t;
 }
 
+// A survivor record's row field (40 bits) with bit 39 set holds the TEXT POSITION of a unique seed instead of its row: the
+// seed table stores SA[k] next to such a seed (count code 0), so the vote stage has nothing to gather for it.  (Rows and
+// positions stay below 2^39: 288 GB of HBM hold no longer text.)
+#define LRM_LOCATED_BIT (1ull << 39)
+__device__ __forceinline__ uint64_t sa_of_unique(const LrmIndexView &ix, uint64_t rec) {
+    const uint64_t kk = rec & ((1ull << 40) - 1ull);
+    return (kk & LRM_LOCATED_BIT) ? (kk & (LRM_LOCATED_BIT - 1ull)) : sa_locate(ix, kk);
+}
+
 // lc_access (lchash.c:12-16) on the 8-byte device entries
 __device__ __forceinline__ void lc_lookup(const LrmIndexView &ix, uint64_t code, uint64_t &k, uint64_t &l) {
     const uint64_t e = ix.lc[code];
@@ -229,6 +238,7 @@ __device__ __forceinline__ int sd_search(const LrmIndexView &ix, const SdKey &ke
     if (e != 0) {
         k = e & ((1ull << ix.sd_kbits) - 1ull);
         c = (e >> ix.sd_kbits) & cmax;
+        if (c == 0) { k |= LRM_LOCATED_BIT; c = 1; return 1; }        // a unique S-mer: the field is SA[k], not k (sa_of_unique)
         if (c != cmax) return 1;
     } else if (!ovf) {
         return 0;
@@ -543,8 +553,14 @@ __global__ __launch_bounds__(256) void sd_build_kernel(LrmIndexView ix, LrmIndex
     if (rr == 0) return;
     if (atomicOr(&claimed[k >> 5], 1u << (k & 31u)) & (1u << (k & 31u))) return;               // another occurrence entered this S-mer
     const uint64_t cmax = (1ull << sdv.sd_cbits) - 1ull;
-    const uint64_t c = rr < cmax ? rr : cmax;
-    const uint64_t side = k | ((rr < 0xFFFFFFull ? rr : 0xFFFFFFull) << 40);
+    uint64_t c = rr < cmax ? rr : cmax;
+    uint64_t side = k | ((rr < 0xFFFFFFull ? rr : 0xFFFFFFull) << 40);
+    if (rr == 1 && sdv.sd_kbits <= 38) {
+        // a unique S-mer takes its text position along (count code 0): most hits of a read come from unique seeds, and every
+        // one of them was a random 64-byte line of the suffix array in the vote stage
+        const uint64_t pos = sa_locate(ix, k);
+        if (pos >= 1 && pos < (1ull << sdv.sd_kbits)) { k = pos; c = 0; side = pos | LRM_LOCATED_BIT | (1ull << 40); }
+    }
     bool to_side = rr >= cmax;
     for (uint32_t r = 0; r < (uint32_t) sdv.sd_f; ++r) {
         const SdKey key = sd_key_of(sdv, code, r);
@@ -1257,7 +1273,7 @@ __device__ __forceinline__ void vote_item_wave(const LrmIndexView &ix, const uin
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const uint32_t rr = (uint32_t) (e[u] >> 40);
-        sv[u] = rr == 1 ? sa_locate(ix, e[u] & ((1ull << 40) - 1ull)) : 0ull;       // unique seeds: gather at once
+        sv[u] = rr == 1 ? sa_of_unique(ix, e[u]) : 0ull;       // unique seeds: gather at once (or nothing to gather)
         const bool big = rr > 1;
         const unsigned long long bm = __ballot(big);
         const uint32_t incl = wave_incl_scan(big ? rr : 0u);
@@ -1362,7 +1378,7 @@ __device__ __forceinline__ void vote_item_block(const LrmIndexView &ix, const ui
             const uint64_t e0 = tid < nc ? rec[c0 + tid] : 0ull;
             const uint32_t q0 = tid < nc ? recq[c0 + tid] : 0u;
             const uint32_t r0 = (uint32_t) (e0 >> 40);
-            const uint64_t v0 = r0 == 1 ? sa_locate(ix, e0 & ((1ull << 40) - 1ull)) : 0ull;
+            const uint64_t v0 = r0 == 1 ? sa_of_unique(ix, e0) : 0ull;
             const uint32_t b0 = r0 > 1 ? 1u : 0u, h0 = b0 ? r0 : 0u;
             const unsigned long long bm = __ballot(b0 != 0), um = __ballot(r0 == 1);
             const uint32_t incl_h = wave_incl_scan(h0);
@@ -1583,7 +1599,7 @@ void vote_fast_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec, const u
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const uint32_t rr = (uint32_t) (e[u] >> 40);
-                sv[u] = rr == 1 ? sa_locate(ix, e[u] & ((1ull << 40) - 1ull)) : 0ull;       // unique seeds: gather at once
+                sv[u] = rr == 1 ? sa_of_unique(ix, e[u]) : 0ull;       // unique seeds: gather at once (or nothing to gather)
                 any_big |= __ballot(rr > 1);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1703,7 +1719,7 @@ void vote_fast_block_kernel(LrmIndexView ix, const uint64_t *__restrict__ rec, c
             any_big |= r0 > 1 ? 1u : 0u;
             if (r0 == 1) {
                 const uint32_t q0 = iq[c0 + tid];
-                const uint64_t v0 = sa_locate(ix, e0 & ((1ull << 40) - 1ull));
+                const uint64_t v0 = sa_of_unique(ix, e0);
                 ok &= vote_admit(t, v0 - (uint64_t) (iter + q0 * P), q0 << tbits, 1u, 0u);
             }
         }
