@@ -495,6 +495,10 @@ def main():
             rank_requests_per_seed=dev_counts["seed_rank_requests"] / dev_counts["seeds_evaluated"],
             vote=per_base["vote"] + 48.0 * (args.seed_len + 1) / Lr,
         )
+        if di_tables.get("seed_table_len") == args.seed_len:
+            # unique seeds come out of the seed table with their text position: their SA rows are not gathered, so the
+            # reference's "8 B per SA hit" is an UPPER bound on what the vote kernels must move on this handle
+            dev_per_base["vote_is_upper_bound"] = True
 
     # ---- per-kernel table and the roofline of the dominant kernel ----------------------------------
     # reference-layout algorithmic bytes per read base per kernel family; device-layout bytes next to them
@@ -503,7 +507,8 @@ def main():
     dev_of = {"pack2bit_kernel": 1.25, "gact_kernel": per_base["gact"], "gact_bs_kernel": per_base["gact"], "bs_pack_reads_kernel": 1.25}
     if dev_per_base:
         dev_of["seed_search_kernel"] = dev_per_base["seed_search"]
-        dev_of["vote_kernel"] = dev_per_base["vote"]
+        if not dev_per_base.get("vote_is_upper_bound"):
+            dev_of["vote_kernel"] = dev_per_base["vote"]
     pmc, pmc_file = load_pmc_summary(args, n, Lr)
 
     def kernel_table(ktimes):
