@@ -120,7 +120,8 @@ typedef struct lrm_index_options {
     int32_t seed_table;        /* SEED table: a hash table of the text's seed_table_len-mers -- (first row, count) of every distinct one,
                                   the exact result of lc_aln + fmi_aln (lchash.c:89-104, fmidx.c:295-313) for it -- in 64-byte lines
                                   that the seeds of 4 (or 2) neighbouring read positions share: a seed of that length costs a quarter
-                                  (half) of a memory line and no backward step.  -1 automatic (pure ACGT texts, when HBM allows: 2 GiB
+                                  (half) of a memory line and no backward step; a 20-mer that occurs once carries its text position
+                                  (sa_access of its row, fmidx.c:18-33), so the vote stage gathers nothing for it.  -1 automatic (pure ACGT texts, when HBM allows: 2 GiB
                                   for an E. coli-sized text, 64 GiB chr1-sized, 128 GiB GRCh38-sized), 0 off, 1 on.  Seeds of any
                                   other length go through the tables above. */
     uint32_t seed_table_len;   /* seed length the table is built for: 0 = 20, the reference's default (alnmain.c:577-580); 16..24 */
