@@ -538,8 +538,8 @@ __global__ __launch_bounds__(256) void core_ovf_kernel(uint64_t *__restrict__ co
 // Seed table build, one lane per text position p: the S-mer at p is searched as a seed would be (through whatever
 // tables the handle already has); the first lane to claim the interval's first row k in a bitmap over the rows (distinct
 // S-mers have disjoint intervals) enters it -- once per distinct S-mer -- into the lines of its F roles.  What does not
-// fit (a full line, a count of cmax or more) goes on the list for the side hash table.  Only the text and the FM index
-// are read, never the suffix array.
+// fit (a full line, a count of cmax or more) goes on the list for the side hash table.  The suffix array is read only
+// for the text position a unique S-mer takes along (deduplication goes by the claimed rows, not by SA values).
 __global__ __launch_bounds__(256) void sd_build_kernel(LrmIndexView ix, LrmIndexView sdv, uint64_t *__restrict__ sd, uint64_t p0,
                                                        uint32_t *__restrict__ claimed,
                                                        uint64_t *__restrict__ ovf, uint64_t ovf_cap, unsigned long long *__restrict__ n_ovf) {
